@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generates the fixtures under tests/golden/generated/ with the fp64 CPU oracle.
+
+The reference's repository lacks two golden files (its .MISSING_LARGE_BLOBS:
+check/256x256.final_state.dat and check/1024x1024.final_state.dat).  This script runs the
+fp64 oracle (oracle/d2q9_oracle.c, OpenMP build — results are thread-count independent) on all
+four shipped inputs for their full length, verifies each run against the shipped golden files
+first (av_vels for all four, final_state for 128x128 and 128x256; print-precision agreement),
+and only then stores, per input:
+
+  generated/<size>.final_state.npz   pressure (f64), u_x/u_y/u (f32), obstacles (u8)   [256², 1024² only]
+  generated/oracle_f64_scalars.json  Reynolds number, mean pressure, av_vels[0], av_vels[-1] per input
+
+Usage (from the repo root, ≈3-4 min on 8 cores):  python tests/golden/make_golden.py
+"""
+import gzip
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.oracle import Oracle  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SIZES = ["128x128", "128x256", "256x256", "1024x1024"]
+
+
+def load_gz_cols(path, cols):
+    with gzip.open(path, "rt") as f:
+        return np.loadtxt(io.StringIO(f.read()), usecols=cols)
+
+
+def max_pcnt(ref, sim):
+    diff = ref - sim
+    return float(np.max(np.abs(100.0 * diff / (ref - diff))))
+
+
+def main():
+    orc = Oracle("f64", omp=True)
+    scalars = {}
+    for size in SIZES:
+        p, obst = orc.load(os.path.join(ROOT, "inputs", "input_%s.params" % size),
+                           os.path.join(ROOT, "inputs", "obstacles_%s.dat" % size))
+        cells = orc.init_cells(p)
+        t0 = time.time()
+        av = orc.run(p, cells, obst, p.max_iters)
+        dt = time.time() - t0
+        ux, uy, u, pr = orc.final_fields(p, cells, obst)
+        ref_av = load_gz_cols(os.path.join(GOLD, "check", "%s.av_vels.dat.gz" % size), [1])
+        # %.12E print precision of the golden files bounds the agreement at ~5e-11 relative
+        e_av = max_pcnt(ref_av, av)
+        assert e_av < 1e-8, (size, e_av)
+        msg = "%s: %d steps in %.1f s, av_vels max %.2e %%" % (size, p.max_iters, dt, e_av)
+        fs = os.path.join(GOLD, "check", "%s.final_state.dat.gz" % size)
+        if os.path.exists(fs):
+            ref_p = load_gz_cols(fs, [5]).reshape(p.ny, p.nx)
+            e_p = max_pcnt(ref_p, pr)
+            assert e_p < 1e-8, (size, e_p)
+            msg += ", pressure max %.2e %%" % e_p
+        else:
+            np.savez_compressed(os.path.join(GOLD, "generated", "%s.final_state.npz" % size),
+                                pressure=pr, u_x=ux.astype(np.float32), u_y=uy.astype(np.float32),
+                                u=u.astype(np.float32), obstacles=obst.astype(np.uint8))
+            msg += ", final_state stored"
+        print(msg, flush=True)
+        scalars[size] = {
+            "reynolds": orc.reynolds(p, cells, obst),
+            "mean_pressure": float(pr.mean()),
+            "av_vels_first": float(av[0]),
+            "av_vels_last": float(av[-1]),
+            "total_density": float(cells.sum()),
+        }
+    with open(os.path.join(GOLD, "generated", "oracle_f64_scalars.json"), "w") as f:
+        json.dump(scalars, f, indent=1, sort_keys=True)
+    print(json.dumps(scalars, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
