@@ -1,0 +1,148 @@
+/*
+ * lbm.h — C ABI of liblbm_hip.so: the MI355X-native D2Q9-BGK timestep.
+ *
+ * This is the drop-in boundary for the reference's host<->device seam.  The reference
+ * (ag14774/OpenCL-Lattice-Boltzmann) has no plugin API; its hot path sits behind the OpenCL
+ * calls made by d2q9-bgk.c.  Each entry point below replaces the cited call site(s); a host
+ * written against this header needs no OpenCL, no kernels.cl and no JIT.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no C++/torch types;
+ *   - every function returns LBM_OK (0) or a non-zero LBM_ERR_* code; lbm_last_error() returns
+ *     the message of the calling thread's most recent failure (the reference's checkError()
+ *     prints such a message and exits, d2q9-bgk.c:858-866 — the host does the same);
+ *   - the caller owns all host arrays (d2q9-bgk.c:519-526,597,720-727); the library owns all
+ *     device memory (d2q9-bgk.c:687-710,729-733);
+ *   - one host thread drives a context; calls are asynchronous on the context's HIP streams and
+ *     ordered like the reference's single in-order queue (d2q9-bgk.c:612-616);
+ *   - cells layout = the reference's SoA: float[9][ny][nx], speed k at k*nx*ny + y*nx + x
+ *     (d2q9-bgk.c:73, kernels.cl:7), speeds numbered 0 rest, 1 E, 2 N, 3 W, 4 S, 5 NE, 6 NW,
+ *     7 SW, 8 SE (d2q9-bgk.c:7-13); obstacles = int32[ny][nx], 0 fluid / non-zero blocked.
+ */
+#ifndef LBM_H
+#define LBM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_OK 0
+#define LBM_ERR_ARG 1    /* bad argument */
+#define LBM_ERR_HIP 2    /* HIP runtime error (message has the hipError string) */
+#define LBM_ERR_STATE 3  /* call not valid in the context's current state */
+#define LBM_ERR_COMM 4   /* RCCL error */
+
+/* Run constants: the reference's t_param (d2q9-bgk.c:81-92), same fields. */
+typedef struct lbm_params {
+  int nx;               /* cells in x */
+  int ny;               /* cells in y */
+  int max_iters;        /* capacity of the av_vels record (steps that can be run) */
+  int reynolds_dim;     /* dimension for the Reynolds number */
+  float density;        /* density per link */
+  float accel;          /* density redistribution */
+  float omega;          /* relaxation parameter */
+  float free_cells_inv; /* 1 / number of non-blocked cells (d2q9-bgk.c:591) */
+} lbm_params;
+
+typedef struct lbm_ctx lbm_ctx; /* opaque; replaces t_ocl (d2q9-bgk.c:97-119) */
+
+/*
+ * Create a context: select device(s), allocate the two cell grids, the obstacle mask and the
+ * reduction buffers.  Replaces selectOpenCLDevice + clCreateContext/Queue/Program/Kernel/Buffer
+ * (d2q9-bgk.c:600-710, 885-944) and the obstacle upload (d2q9-bgk.c:205-209).
+ *   obstacles  borrowed for the duration of the call.
+ *   ndev       number of row slabs; the grid is row-partitioned over dev_ids[0..ndev).  ndev <= 1
+ *              with dev_ids == NULL uses the current HIP device.  A device may be listed more than
+ *              once (several slabs on one GPU): halos then move by device-to-device copies instead
+ *              of RCCL.  Requires ny >= 2*ndev... rows per slab >= 2.
+ */
+int lbm_create(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles, int ndev, const int *dev_ids);
+
+/*
+ * One-process-per-GPU form (torchrun / MPI style launch): this process owns slab `rank` of
+ * `nranks` on HIP device `device`; halos are exchanged with ranks (rank±1) mod nranks by RCCL
+ * send/recv and the velocity sums are combined by an RCCL all-reduce.  `comm_id` is the
+ * lbm_comm_id_size()-byte blob produced by lbm_comm_get_id() on one rank and distributed by the
+ * caller (e.g. torch.distributed broadcast).  params/obstacles describe the GLOBAL grid.
+ * No counterpart in the reference (single device); mandated by the multi-GPU configs.
+ */
+int lbm_create_rank(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles,
+                    int rank, int nranks, int device, const void *comm_id);
+size_t lbm_comm_id_size(void);
+int lbm_comm_get_id(void *comm_id_out);
+
+/*
+ * Host -> device copy of the initial state.  Replaces clEnqueueWriteBuffer(cells)
+ * (d2q9-bgk.c:200-203).  cells == NULL initialises the uniform rest state on the device
+ * (the values of d2q9-bgk.c:529-550) without any host transfer.  Resets the step counter.
+ * In rank mode `cells` is the GLOBAL array; only this rank's rows are read.
+ */
+int lbm_upload(lbm_ctx *ctx, const float *cells);
+
+/*
+ * Advance nsteps timesteps (accelerate_flow + timestep + av_vels reduction each); asynchronous.
+ * Replaces the loop body d2q9-bgk.c:221-238 (accelerate_flow(), timestep(), reduce() wrappers,
+ * d2q9-bgk.c:282-393).  May be called repeatedly; after n calls' worth of steps exactly that many
+ * steps have been applied and av_vels[t] is defined for every one of them.
+ */
+int lbm_run(lbm_ctx *ctx, int nsteps);
+
+/* lbm_run + device-side timing: *ms = elapsed time of the nsteps step loop measured with HIP
+ * events recorded on the stream the kernels run on (max over slabs).  Synchronises. */
+int lbm_run_timed(lbm_ctx *ctx, int nsteps, double *ms);
+
+/* Wait for all queued work.  Replaces clFinish (d2q9-bgk.c:239). */
+int lbm_sync(lbm_ctx *ctx);
+
+/*
+ * Device -> host.  Replaces the two clEnqueueReadBuffer calls (d2q9-bgk.c:251-260).  Either
+ * pointer may be NULL.  cells_out receives the CURRENT state whatever the step parity (the
+ * reference reads a fixed buffer, correct only for even step counts).  av_vels_out receives
+ * lbm_steps_done() floats.  Synchronises.  In rank mode cells_out is the GLOBAL array and only
+ * this rank's rows are written; av_vels_out is the all-reduced global record.
+ */
+int lbm_download(lbm_ctx *ctx, float *cells_out, float *av_vels_out);
+
+/* Steps applied since the last lbm_upload. */
+int lbm_steps_done(const lbm_ctx *ctx);
+
+/* Rows [*y0, *y1) of the global grid held by this context (whole grid unless rank mode). */
+int lbm_row_range(const lbm_ctx *ctx, int *y0, int *y1);
+
+/*
+ * Output stage on the device: the per-cell columns of final_state.dat (d2q9-bgk.c:787-832:
+ * u_x, u_y, speed u, pressure; obstacle cells give 0,0,0,density/3) and the Reynolds number of
+ * the current state (av_velocity + calc_reynolds, d2q9-bgk.c:396-442,747-752).  Each output is
+ * float[ny][nx] (rank mode: global array, own rows written) and may be NULL.  Synchronises.
+ */
+int lbm_final_state(lbm_ctx *ctx, float *u_x, float *u_y, float *u, float *pressure);
+int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
+
+/*
+ * Tuning knobs (all optional; defaults are the measured-best on MI355X):
+ *   "variant"      0 = auto, 1 = direct-load kernel, 2 = wave-shuffle kernel, 3 = LDS-staged kernel
+ *   "grid_blocks"  cap on workgroups per launch (0 = auto)
+ *   "nt_stores"    1 = non-temporal stores for the destination grid, 0 = plain, -1 = auto
+ *   "use_graph"    1 = replay the step loop from a hipGraph, 0 = eager launches, -1 = auto
+ *   "transport"    0 = auto, 1 = RCCL send/recv, 2 = device-to-device copies (single process only)
+ */
+int lbm_set_option(lbm_ctx *ctx, const char *key, long value);
+int lbm_get_option(const lbm_ctx *ctx, const char *key, long *value);
+
+/* Roofline denominator: float4 device-to-device copy kernel (read bytes + written bytes per
+ * second, in GB/s) on the current device; bytes is the size of each of the two buffers. */
+int lbm_copy_bandwidth(size_t bytes, int iters, double *gbps);
+
+/* Release everything.  Replaces the clRelease* block of finalise (d2q9-bgk.c:729-741). */
+void lbm_destroy(lbm_ctx *ctx);
+
+const char *lbm_last_error(void);
+const char *lbm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBM_H */

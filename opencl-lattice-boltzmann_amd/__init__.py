@@ -1,0 +1,248 @@
+"""opencl-lattice-boltzmann_amd — MI355X-native D2Q9-BGK lattice-Boltzmann timestep.
+
+Host-side mirror of the C ABI in include/lbm.h (liblbm_hip.so, hand-written HIP for gfx950).
+The product's host is the C program `d2q9-bgk` (host/d2q9-bgk.c); this module is the ctypes
+binding used by bench.py, __graft_entry__.py and the tests.  There is NO CPU fallback: loading
+fails loudly when the HIP library is missing, and every entry point raises LBMError on a non-zero
+return code (the reference's checkError() prints and exits, d2q9-bgk.c:858-866).
+
+The directory name contains '-' and is therefore loaded through `lbm_amd.py` at the repo root
+(`import lbm_amd`).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "liblbm_hip.so")
+
+# every symbol include/lbm.h declares
+ABI_SYMBOLS = [
+    "lbm_create", "lbm_create_rank", "lbm_comm_id_size", "lbm_comm_get_id", "lbm_upload", "lbm_run",
+    "lbm_run_timed", "lbm_sync", "lbm_download", "lbm_steps_done", "lbm_row_range", "lbm_final_state",
+    "lbm_reynolds", "lbm_set_option", "lbm_get_option", "lbm_copy_bandwidth", "lbm_destroy",
+    "lbm_last_error", "lbm_version",
+]
+
+
+class LBMError(RuntimeError):
+    pass
+
+
+class Params(ctypes.Structure):
+    """lbm_params == the reference's t_param (d2q9-bgk.c:81-92)."""
+    _fields_ = [("nx", ctypes.c_int), ("ny", ctypes.c_int), ("max_iters", ctypes.c_int),
+                ("reynolds_dim", ctypes.c_int), ("density", ctypes.c_float), ("accel", ctypes.c_float),
+                ("omega", ctypes.c_float), ("free_cells_inv", ctypes.c_float)]
+
+
+def build_library(verbose=False):
+    """Compile liblbm_hip.so and the d2q9-bgk host for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.run(["make", "-C", ROOT, "-j4", "all"], check=True, stdout=out)
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen liblbm_hip.so and declare the prototypes of include/lbm.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LBMError("HIP library %s is missing: run `make` (or __graft_entry__.build()); "
+                       "there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p
+    L.lbm_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(Params), vp, ci, ctypes.POINTER(ci)]
+    L.lbm_create_rank.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(Params), vp, ci, ci, ci, vp]
+    L.lbm_comm_id_size.restype = ctypes.c_size_t
+    L.lbm_comm_get_id.argtypes = [vp]
+    L.lbm_upload.argtypes = [vp, vp]
+    L.lbm_run.argtypes = [vp, ci]
+    L.lbm_run_timed.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
+    L.lbm_sync.argtypes = [vp]
+    L.lbm_download.argtypes = [vp, vp, vp]
+    L.lbm_steps_done.argtypes = [vp]
+    L.lbm_row_range.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.lbm_final_state.argtypes = [vp, vp, vp, vp, vp]
+    L.lbm_reynolds.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.lbm_set_option.argtypes = [vp, cp, ctypes.c_long]
+    L.lbm_get_option.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_long)]
+    L.lbm_copy_bandwidth.argtypes = [ctypes.c_size_t, ci, ctypes.POINTER(ctypes.c_double)]
+    L.lbm_destroy.argtypes = [vp]
+    L.lbm_destroy.restype = None
+    L.lbm_last_error.restype = cp
+    L.lbm_version.restype = cp
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise LBMError("%s failed (code %d): %s" % (what, rc, load_library().lbm_last_error().decode()))
+
+
+def make_params(nx, ny, max_iters, reynolds_dim=10, density=0.1, accel=0.005, omega=1.85, obstacles=None):
+    """Run constants; free_cells_inv from the mask as in d2q9-bgk.c:583-591."""
+    p = Params()
+    p.nx, p.ny, p.max_iters, p.reynolds_dim = nx, ny, max_iters, reynolds_dim
+    p.density, p.accel, p.omega = density, accel, omega
+    free_cells = nx * ny if obstacles is None else int(obstacles.size - np.count_nonzero(obstacles))
+    p.free_cells_inv = np.float32(1.0) / np.float32(free_cells)
+    return p
+
+
+def read_inputs(paramfile, obstaclefile):
+    """Parse the reference's two input files (d2q9-bgk.c:466-492, 553-591) into (Params, mask)."""
+    with open(paramfile) as f:
+        tok = f.read().split()
+    if len(tok) < 7:
+        raise ValueError("could not read param file: %s" %
+                         ["nx", "ny", "maxIters", "reynolds_dim", "density", "accel", "omega"][len(tok)])
+    nx, ny, max_iters, reynolds_dim = (int(t) for t in tok[:4])
+    density, accel, omega = (float(t) for t in tok[4:7])
+    obstacles = np.zeros((ny, nx), dtype=np.int32)
+    with open(obstaclefile) as f:
+        vals = f.read().split()
+    if len(vals) % 3:
+        raise ValueError("expected 3 values per line in obstacle file")
+    if vals:
+        tri = np.array(vals, dtype=np.int64).reshape(-1, 3)
+        if np.any(tri[:, 0] < 0) or np.any(tri[:, 0] > nx - 1):
+            raise ValueError("obstacle x-coord out of range")
+        if np.any(tri[:, 1] < 0) or np.any(tri[:, 1] > ny - 1):
+            raise ValueError("obstacle y-coord out of range")
+        if np.any(tri[:, 2] != 1):
+            raise ValueError("obstacle blocked value should be 1")
+        obstacles[tri[:, 1], tri[:, 0]] = 1
+    return make_params(nx, ny, max_iters, reynolds_dim, density, accel, omega, obstacles), obstacles
+
+
+def copy_bandwidth_gbps(nbytes=1 << 30, iters=20):
+    """Measured float4 streaming-copy rate (read + write bytes per second) — the roofline denominator."""
+    g = ctypes.c_double()
+    _check(load_library().lbm_copy_bandwidth(nbytes, iters, ctypes.byref(g)), "lbm_copy_bandwidth")
+    return g.value
+
+
+def comm_id():
+    """RCCL unique id blob for lbm_create_rank (produce on one rank, broadcast to the others)."""
+    L = load_library()
+    buf = ctypes.create_string_buffer(L.lbm_comm_id_size())
+    _check(L.lbm_comm_get_id(buf), "lbm_comm_get_id")
+    return buf.raw
+
+
+class LBM:
+    """A simulation context (lbm_ctx).  Mirrors the call sequence of the reference's main()
+    (d2q9-bgk.c:194-277): create -> upload -> run -> sync -> download -> destroy."""
+
+    def __init__(self, params, obstacles, devices=None, rank=None, nranks=None, device=0, comm=None):
+        self.lib = load_library()
+        self.params = params
+        self.nx, self.ny = params.nx, params.ny
+        obst = np.ascontiguousarray(obstacles, dtype=np.int32)
+        assert obst.shape == (params.ny, params.nx)
+        self.obstacles = obst
+        self.ctx = ctypes.c_void_p()
+        if rank is not None:
+            cid = ctypes.create_string_buffer(comm, len(comm)) if comm is not None else None
+            _check(self.lib.lbm_create_rank(ctypes.byref(self.ctx), ctypes.byref(params), obst.ctypes.data,
+                                            rank, nranks, device, cid), "lbm_create_rank")
+        elif devices is None:
+            _check(self.lib.lbm_create(ctypes.byref(self.ctx), ctypes.byref(params), obst.ctypes.data, 1, None),
+                   "lbm_create")
+        else:
+            arr = (ctypes.c_int * len(devices))(*devices)
+            _check(self.lib.lbm_create(ctypes.byref(self.ctx), ctypes.byref(params), obst.ctypes.data,
+                                       len(devices), arr), "lbm_create")
+
+    def upload(self, cells=None):
+        if cells is None:
+            _check(self.lib.lbm_upload(self.ctx, None), "lbm_upload")
+        else:
+            c = np.ascontiguousarray(cells, dtype=np.float32)
+            assert c.shape == (9, self.ny, self.nx)
+            _check(self.lib.lbm_upload(self.ctx, c.ctypes.data), "lbm_upload")
+
+    def run(self, nsteps):
+        _check(self.lib.lbm_run(self.ctx, nsteps), "lbm_run")
+
+    def run_timed(self, nsteps):
+        """Runs nsteps and returns the HIP-event time of the step loop in milliseconds."""
+        ms = ctypes.c_double()
+        _check(self.lib.lbm_run_timed(self.ctx, nsteps, ctypes.byref(ms)), "lbm_run_timed")
+        return ms.value
+
+    def sync(self):
+        _check(self.lib.lbm_sync(self.ctx), "lbm_sync")
+
+    @property
+    def steps_done(self):
+        return self.lib.lbm_steps_done(self.ctx)
+
+    def row_range(self):
+        y0, y1 = ctypes.c_int(), ctypes.c_int()
+        _check(self.lib.lbm_row_range(self.ctx, ctypes.byref(y0), ctypes.byref(y1)), "lbm_row_range")
+        return y0.value, y1.value
+
+    def download(self, cells=True, av_vels=True):
+        """Returns (cells float32[9,ny,nx] or None, av_vels float32[steps_done] or None)."""
+        c = np.zeros((9, self.ny, self.nx), dtype=np.float32) if cells else None
+        a = np.zeros(max(self.steps_done, 1), dtype=np.float32) if av_vels else None
+        _check(self.lib.lbm_download(self.ctx, c.ctypes.data if cells else None,
+                                     a.ctypes.data if av_vels else None), "lbm_download")
+        return c, (a[:self.steps_done] if av_vels else None)
+
+    def final_state(self):
+        """(u_x, u_y, u, pressure), each float32[ny,nx] — the columns of final_state.dat."""
+        outs = [np.zeros((self.ny, self.nx), dtype=np.float32) for _ in range(4)]
+        _check(self.lib.lbm_final_state(self.ctx, *[o.ctypes.data for o in outs]), "lbm_final_state")
+        return outs
+
+    def reynolds(self):
+        r = ctypes.c_float()
+        _check(self.lib.lbm_reynolds(self.ctx, ctypes.byref(r)), "lbm_reynolds")
+        return r.value
+
+    def set_option(self, key, value):
+        _check(self.lib.lbm_set_option(self.ctx, key.encode(), int(value)), "lbm_set_option(%s)" % key)
+
+    def get_option(self, key):
+        v = ctypes.c_long()
+        _check(self.lib.lbm_get_option(self.ctx, key.encode(), ctypes.byref(v)), "lbm_get_option(%s)" % key)
+        return v.value
+
+    def write_values(self, final_state_path="final_state.dat", av_vels_path="av_vels.dat"):
+        """The two output files in the reference's format (d2q9-bgk.c:835,848-851)."""
+        ux, uy, u, pr = self.final_state()
+        _, av = self.download(cells=False)
+        yy, xx = np.mgrid[0:self.ny, 0:self.nx]
+        cols = np.stack([xx.ravel(), yy.ravel(), ux.ravel(), uy.ravel(), u.ravel(), pr.ravel(),
+                         self.obstacles.ravel()], axis=1)
+        np.savetxt(final_state_path, cols, fmt=["%d", "%d", "%.12E", "%.12E", "%.12E", "%.12E", "%d"])
+        with open(av_vels_path, "w") as f:
+            for i, v in enumerate(av):
+                f.write("%d:\t%.12E\n" % (i, v))
+
+    def close(self):
+        if self.ctx:
+            self.lib.lbm_destroy(self.ctx)
+            self.ctx = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,332 @@
+// Device code of liblbm_hip.so: the fused D2Q9-BGK timestep for gfx950 (MI355X, CDNA4).
+//
+// What one launch of d2q9_step computes is the reference's accelerate_flow + timestep kernels
+// (kernels.cl:9-53, 56-231) for a range of rows:
+//   pull-stream gather with periodic wrap   kernels.cl:91-114
+//   density / momenta / equilibria / BGK    kernels.cl:119-185
+//   bounce-back on obstacle cells           kernels.cl:69,187-197
+//   per-cell |j|/rho summed per workgroup   kernels.cl:198-229
+// plus, on the row ny-2, the NEXT step's accelerate_flow applied while the row is still in
+// registers (exact: accelerate_flow is local to a cell and runs directly before the next gather).
+//
+// Data layout in HBM (one grid): 9 planes of rows*nx floats, plane k at k*plane_stride, x fastest
+// — the reference's SoA (d2q9-bgk.c:73) with a padded plane stride.  The obstacle mask is one
+// byte per cell.  Every thread owns VEC=4 consecutive cells of one row: all 9 loads and all 9
+// stores of a wave are whole 1-KiB contiguous segments (64 lanes x 16 B).
+//
+// Not a translation of kernels.cl: different work decomposition (float4 rows, grid-stride,
+// wave64 shuffles), different arithmetic grouping (pairwise momentum differences, shared
+// equilibrium terms), fused accelerate, byte mask, deterministic two-stage reduction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lbm {
+
+constexpr int kBlock = 256;  // 4 wave64 per workgroup
+
+struct StepArgs {
+  const float *src;           // plane 0 of the source grid
+  float *dst;                 // plane 0 of the destination grid
+  const uint8_t *mask;        // [rows][nx], non-zero = obstacle
+  const float *south_src[3];  // row "y-1" of planes 2,5,6 for y == 0 (periodic wrap row or received halo)
+  const float *north_src[3];  // row "y+1" of planes 4,7,8 for y == rows-1
+  float *send_south;          // [3][nx]: planes 4,7,8 of the new row 0, or nullptr
+  float *send_north;          // [3][nx]: planes 2,5,6 of the new row rows-1, or nullptr
+  float *partials;            // [gridDim.x] per-workgroup sums of |j|/rho
+  unsigned long long plane_stride;  // floats between planes
+  int nx, rows;               // row length, rows held in this grid
+  int y_begin, y_count, y_step;  // rows y_begin + r*y_step, r < y_count, are processed
+  int accel_row;              // local row that gets the next step's accelerate_flow, or -1
+  float omega, aw1, aw2;      // relaxation; density*accel/9, density*accel/36 (kernels.cl:14-15)
+};
+
+// ---- small helpers ----------------------------------------------------------------------
+
+__device__ __forceinline__ float wave_sum(float v) {
+  // wave64 butterfly; every lane ends with the total
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ void store4(float *p, float a, float b, float c, float d) {
+  v4f v = {a, b, c, d};
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+  else *reinterpret_cast<v4f *>(p) = v;
+}
+
+// BGK collision of one cell on the gathered distributions g[0..8]; writes the new cell to out[].
+// Returns |j|/rho for a fluid cell, 0 for an obstacle.  Arithmetic of kernels.cl:119-198 with
+//  - momenta from pairwise differences (a cell at rest has exactly zero momentum in fp32),
+//  - eq_k = w_k*(rho + 3 j_k + (1.5/rho)(3 j_k^2 - j^2)) regrouped around the shared term
+//    c = rho - (1.5/rho) j^2.
+__device__ __forceinline__ float collide_cell(const float (&g)[9], bool obstacle, float omega, float (&out)[9]) {
+  const float w0 = 4.0f / 9.0f, w1 = 1.0f / 9.0f, w2 = 1.0f / 36.0f;
+  float dens = g[0] + g[1];
+  dens += g[2]; dens += g[3]; dens += g[4]; dens += g[5]; dens += g[6]; dens += g[7]; dens += g[8];
+  const float densinv = __builtin_amdgcn_rcpf(dens);
+  const float da = g[5] - g[7], db = g[8] - g[6];
+  const float jx = (g[1] - g[3]) + (da + db);
+  const float jy = (g[2] - g[4]) + (da - db);
+  const float usq = jx * jx + jy * jy;
+  const float h = 1.5f * densinv;           // 0.5 * densinv * ic_sq
+  const float c = dens - h * usq;           // shared by all nine equilibria
+  const float h3 = 3.0f * h;
+  const float jp = jx + jy, jm = jx - jy;
+  const float ax = c + h3 * jx * jx, ay = c + h3 * jy * jy;
+  const float ap = c + h3 * jp * jp, am = c + h3 * jm * jm;
+  float eq[9];
+  eq[0] = w0 * c;
+  eq[1] = w1 * (ax + 3.0f * jx);
+  eq[3] = w1 * (ax - 3.0f * jx);
+  eq[2] = w1 * (ay + 3.0f * jy);
+  eq[4] = w1 * (ay - 3.0f * jy);
+  eq[5] = w2 * (ap + 3.0f * jp);
+  eq[7] = w2 * (ap - 3.0f * jp);
+  eq[8] = w2 * (am + 3.0f * jm);
+  eq[6] = w2 * (am - 3.0f * jm);
+  // fluid: relax towards equilibrium; obstacle: the un-relaxed value leaves through the opposite
+  // speed (kernels.cl:69 lookup table: 0<->0, 1<->3, 2<->4, 5<->7, 6<->8)
+  out[0] = obstacle ? g[0] : g[0] + omega * (eq[0] - g[0]);
+  out[1] = obstacle ? g[3] : g[1] + omega * (eq[1] - g[1]);
+  out[2] = obstacle ? g[4] : g[2] + omega * (eq[2] - g[2]);
+  out[3] = obstacle ? g[1] : g[3] + omega * (eq[3] - g[3]);
+  out[4] = obstacle ? g[2] : g[4] + omega * (eq[4] - g[4]);
+  out[5] = obstacle ? g[7] : g[5] + omega * (eq[5] - g[5]);
+  out[6] = obstacle ? g[8] : g[6] + omega * (eq[6] - g[6]);
+  out[7] = obstacle ? g[5] : g[7] + omega * (eq[7] - g[7]);
+  out[8] = obstacle ? g[6] : g[8] + omega * (eq[8] - g[8]);
+  return obstacle ? 0.0f : __builtin_amdgcn_sqrtf(usq) * densinv;
+}
+
+// accelerate_flow on one cell held in registers (kernels.cl:24-42)
+__device__ __forceinline__ void accelerate_cell(float (&f)[9], bool obstacle, float aw1, float aw2) {
+  if (!obstacle && (f[3] - aw1) > 0.0f && (f[6] - aw2) > 0.0f && (f[7] - aw2) > 0.0f) {
+    f[1] += aw1; f[5] += aw2; f[8] += aw2;
+    f[3] -= aw1; f[6] -= aw2; f[7] -= aw2;
+  }
+}
+
+// workgroup sum -> partials[blockIdx.x]; fixed order, no atomics (deterministic)
+__device__ __forceinline__ void block_store_partial(float v, float *partials) {
+  __shared__ float wsum[kBlock / 64];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = wsum[0];
+    for (int i = 1; i < kBlock / 64; i++) t += wsum[i];
+    partials[blockIdx.x] = t;
+  }
+}
+
+// ---- variant 1: direct loads ---------------------------------------------------------------
+// Each thread loads its 9 aligned float4 (VEC=4) and, for the six x-shifted planes, the one
+// neighbouring element from the adjacent thread's segment (an L1 hit: the line is being loaded by
+// that thread anyway).  HBM traffic is exactly 9 floats in + 9 floats out + 1 mask byte per cell.
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void d2q9_step_direct(const StepArgs a) {
+  const unsigned tpr = (unsigned)a.nx / VEC;  // threads per row
+  const unsigned total = tpr * (unsigned)a.y_count;
+  const size_t ps = a.plane_stride;
+  float tot_u = 0.0f;
+
+  for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
+    const unsigned r = t / tpr;
+    const int x0 = (int)(t - r * tpr) * VEC;
+    const int y = a.y_begin + (int)r * a.y_step;
+    const size_t row = (size_t)y * a.nx;
+    // neighbour columns with periodic wrap (kernels.cl:99-102)
+    const int xw = (x0 == 0) ? a.nx - 1 : x0 - 1;
+    const int xe = (x0 + VEC >= a.nx) ? 0 : x0 + VEC;
+    // source rows: same row for planes 0,1,3; south row for 2,5,6; north row for 4,7,8
+    const float *rc = a.src + row;
+    const bool at_south = (y == 0), at_north = (y == a.rows - 1);
+    const float *r2 = at_south ? a.south_src[0] : a.src + 2 * ps + row - a.nx;
+    const float *r5 = at_south ? a.south_src[1] : a.src + 5 * ps + row - a.nx;
+    const float *r6 = at_south ? a.south_src[2] : a.src + 6 * ps + row - a.nx;
+    const float *r4 = at_north ? a.north_src[0] : a.src + 4 * ps + row + a.nx;
+    const float *r7 = at_north ? a.north_src[1] : a.src + 7 * ps + row + a.nx;
+    const float *r8 = at_north ? a.north_src[2] : a.src + 8 * ps + row + a.nx;
+    const float *r1 = rc + 1 * ps, *r3 = rc + 3 * ps;
+
+    float g[9][VEC];
+    bool obst[VEC];
+    if constexpr (VEC == 4) {
+      // issue all loads before any use
+      const float4 c0 = *reinterpret_cast<const float4 *>(rc + x0);
+      const float4 c1 = *reinterpret_cast<const float4 *>(r1 + x0);
+      const float4 c2 = *reinterpret_cast<const float4 *>(r2 + x0);
+      const float4 c3 = *reinterpret_cast<const float4 *>(r3 + x0);
+      const float4 c4 = *reinterpret_cast<const float4 *>(r4 + x0);
+      const float4 c5 = *reinterpret_cast<const float4 *>(r5 + x0);
+      const float4 c6 = *reinterpret_cast<const float4 *>(r6 + x0);
+      const float4 c7 = *reinterpret_cast<const float4 *>(r7 + x0);
+      const float4 c8 = *reinterpret_cast<const float4 *>(r8 + x0);
+      const float w1 = r1[xw], w5 = r5[xw], w8 = r8[xw];
+      const float e3 = r3[xe], e6 = r6[xe], e7 = r7[xe];
+      const uint32_t m = *reinterpret_cast<const uint32_t *>(a.mask + row + x0);
+      g[0][0] = c0.x; g[0][1] = c0.y; g[0][2] = c0.z; g[0][3] = c0.w;
+      g[2][0] = c2.x; g[2][1] = c2.y; g[2][2] = c2.z; g[2][3] = c2.w;
+      g[4][0] = c4.x; g[4][1] = c4.y; g[4][2] = c4.z; g[4][3] = c4.w;
+      g[1][0] = w1;   g[1][1] = c1.x; g[1][2] = c1.y; g[1][3] = c1.z;   // from x-1
+      g[5][0] = w5;   g[5][1] = c5.x; g[5][2] = c5.y; g[5][3] = c5.z;
+      g[8][0] = w8;   g[8][1] = c8.x; g[8][2] = c8.y; g[8][3] = c8.z;
+      g[3][0] = c3.y; g[3][1] = c3.z; g[3][2] = c3.w; g[3][3] = e3;     // from x+1
+      g[6][0] = c6.y; g[6][1] = c6.z; g[6][2] = c6.w; g[6][3] = e6;
+      g[7][0] = c7.y; g[7][1] = c7.z; g[7][2] = c7.w; g[7][3] = e7;
+      obst[0] = (m & 0xffu) != 0; obst[1] = (m & 0xff00u) != 0;
+      obst[2] = (m & 0xff0000u) != 0; obst[3] = (m & 0xff000000u) != 0;
+    } else {
+      g[0][0] = rc[x0]; g[1][0] = r1[xw]; g[2][0] = r2[x0]; g[3][0] = r3[xe]; g[4][0] = r4[x0];
+      g[5][0] = r5[xw]; g[6][0] = r6[xe]; g[7][0] = r7[xe]; g[8][0] = r8[xw];
+      obst[0] = a.mask[row + x0] != 0;
+    }
+
+    float o[9][VEC];
+    const bool accel_here = (y == a.accel_row);
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+      float gc[9], oc[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) gc[k] = g[k][v];
+      tot_u += collide_cell(gc, obst[v], a.omega, oc);
+      if (accel_here) accelerate_cell(oc, obst[v], a.aw1, a.aw2);
+#pragma unroll
+      for (int k = 0; k < 9; k++) o[k][v] = oc[k];
+    }
+
+    float *d = a.dst + row + x0;
+    if constexpr (VEC == 4) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) store4<NT>(d + k * ps, o[k][0], o[k][1], o[k][2], o[k][3]);
+      if (a.send_south != nullptr && at_south) {
+        store4<false>(a.send_south + 0 * a.nx + x0, o[4][0], o[4][1], o[4][2], o[4][3]);
+        store4<false>(a.send_south + 1 * a.nx + x0, o[7][0], o[7][1], o[7][2], o[7][3]);
+        store4<false>(a.send_south + 2 * a.nx + x0, o[8][0], o[8][1], o[8][2], o[8][3]);
+      }
+      if (a.send_north != nullptr && at_north) {
+        store4<false>(a.send_north + 0 * a.nx + x0, o[2][0], o[2][1], o[2][2], o[2][3]);
+        store4<false>(a.send_north + 1 * a.nx + x0, o[5][0], o[5][1], o[5][2], o[5][3]);
+        store4<false>(a.send_north + 2 * a.nx + x0, o[6][0], o[6][1], o[6][2], o[6][3]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) d[k * ps] = o[k][0];
+      if (a.send_south != nullptr && at_south) {
+        a.send_south[0 * a.nx + x0] = o[4][0]; a.send_south[1 * a.nx + x0] = o[7][0]; a.send_south[2 * a.nx + x0] = o[8][0];
+      }
+      if (a.send_north != nullptr && at_north) {
+        a.send_north[0 * a.nx + x0] = o[2][0]; a.send_north[1 * a.nx + x0] = o[5][0]; a.send_north[2 * a.nx + x0] = o[6][0];
+      }
+    }
+  }
+  block_store_partial(tot_u, a.partials);
+}
+
+// ---- second reduction stage ------------------------------------------------------------------
+// One workgroup per buffered step: sums that step's per-workgroup partials in a fixed order into
+// av_sum[first + blockIdx.x] (double).  Replaces the reference's multi-pass reduce kernel
+// (kernels.cl:234-290) and its in-place pass results.
+__global__ __launch_bounds__(kBlock) void reduce_partials(const float *partials, int nb, double *av_sum) {
+  const float *p = partials + (size_t)blockIdx.x * nb;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += kBlock) acc += (double)p[i];
+  __shared__ double wsum[kBlock / 64];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = wsum[0];
+    for (int i = 1; i < kBlock / 64; i++) t += wsum[i];
+    av_sum[blockIdx.x] = t;
+  }
+}
+
+// ---- stand-alone accelerate_flow (kernels.cl:9-53): prologue of a run ---------------------------
+__global__ void accelerate_row(float *cells, unsigned long long plane_stride, const uint8_t *mask, int nx, int row,
+                               float aw1, float aw2) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const size_t c = (size_t)row * nx + x;
+  float f3 = cells[3 * plane_stride + c], f6 = cells[6 * plane_stride + c], f7 = cells[7 * plane_stride + c];
+  if (mask[c] == 0 && (f3 - aw1) > 0.0f && (f6 - aw2) > 0.0f && (f7 - aw2) > 0.0f) {
+    cells[1 * plane_stride + c] += aw1;
+    cells[5 * plane_stride + c] += aw2;
+    cells[8 * plane_stride + c] += aw2;
+    cells[3 * plane_stride + c] = f3 - aw1;
+    cells[6 * plane_stride + c] = f6 - aw2;
+    cells[7 * plane_stride + c] = f7 - aw2;
+  }
+}
+
+// packs the boundary rows of a grid into the halo send buffers (start of a run, slab mode)
+__global__ void pack_halo_rows(const float *cells, unsigned long long plane_stride, int nx, int rows,
+                               float *send_south, float *send_north) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nx) return;
+  const size_t top = (size_t)(rows - 1) * nx + x;
+  send_south[0 * nx + x] = cells[4 * plane_stride + x];
+  send_south[1 * nx + x] = cells[7 * plane_stride + x];
+  send_south[2 * nx + x] = cells[8 * plane_stride + x];
+  send_north[0 * nx + x] = cells[2 * plane_stride + top];
+  send_north[1 * nx + x] = cells[5 * plane_stride + top];
+  send_north[2 * nx + x] = cells[6 * plane_stride + top];
+}
+
+// ---- initial state on the device (values of d2q9-bgk.c:529-550) ---------------------------------
+__global__ void init_cells(float *cells, unsigned long long plane_stride, size_t n, float w0, float w1, float w2) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    cells[i] = w0;
+#pragma unroll
+    for (int k = 1; k <= 4; k++) cells[k * plane_stride + i] = w1;
+#pragma unroll
+    for (int k = 5; k <= 8; k++) cells[k * plane_stride + i] = w2;
+  }
+}
+
+// ---- output stage: columns of final_state.dat + velocity sum (d2q9-bgk.c:787-832, 396-442) ------
+__global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsigned long long plane_stride,
+                                                       const uint8_t *mask, size_t n, float density, float *u_x,
+                                                       float *u_y, float *u, float *pressure, float *partials) {
+  const float c_sq = 1.0f / 3.0f;
+  float tot_u = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    float ux = 0.0f, uy = 0.0f, uu = 0.0f, pr = density * c_sq;
+    if (mask[i] == 0) {
+      float f[9];
+      float local_density = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        f[k] = cells[k * plane_stride + i];
+        local_density += f[k];
+      }
+      ux = (f[1] + f[5] + f[8] - f[3] - f[6] - f[7]) / local_density;
+      uy = (f[2] + f[5] + f[6] - f[4] - f[7] - f[8]) / local_density;
+      uu = sqrtf(ux * ux + uy * uy);
+      pr = local_density * c_sq;
+      tot_u += uu;
+    }
+    if (u_x) u_x[i] = ux;
+    if (u_y) u_y[i] = uy;
+    if (u) u[i] = uu;
+    if (pressure) pressure[i] = pr;
+  }
+  block_store_partial(tot_u, partials);
+}
+
+// ---- roofline denominator: float4 streaming copy ---------------------------------------------
+__global__ __launch_bounds__(kBlock) void copy_f4(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = in[i];
+}
+
+}  // namespace lbm

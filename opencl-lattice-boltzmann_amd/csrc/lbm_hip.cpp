@@ -1,0 +1,871 @@
+// liblbm_hip.so — host side of the C ABI declared in include/lbm.h (compiled with hipcc for gfx950).
+//
+// Replaces the reference's host<->device seam: context/queue/program/buffer setup
+// (d2q9-bgk.c:600-710), the kernel-launch wrappers accelerate_flow()/timestep()/reduce()
+// (d2q9-bgk.c:282-393), the ping-pong step loop (d2q9-bgk.c:214-239), the transfers
+// (d2q9-bgk.c:200-209,251-260) and the releases (d2q9-bgk.c:729-741).
+//
+// Structure: a context owns one or more row SLABS.  A slab is a contiguous range of grid rows on
+// one GPU with its own pair of grids, mask, streams and reduction buffers.  With one slab the y
+// wrap-around is resolved inside the kernel (the "halo" rows are the slab's own first/last rows).
+// With several slabs each slab's two edge rows are computed first on an edge stream, their three
+// outgoing distributions are packed by the kernel into send buffers and exchanged with the ring
+// neighbours (RCCL send/recv over xGMI, or device-to-device copies when slabs share a process and
+// RCCL cannot be used), while the interior rows are computed on the main stream.
+#include "../../include/lbm.h"
+#include "d2q9_kernels.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(LBM_ERR_HIP, "HIP error during '%s' (%s:%d): %s", #expr, __FILE__, __LINE__, \
+                  hipGetErrorString(e_));                                                      \
+  } while (0)
+
+// ---- RCCL, loaded on first multi-GPU use (a single-GPU run never touches it) ------------------
+struct Rccl {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.handle) return LBM_OK;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(LBM_ERR_COMM, "cannot load librccl: %s", dlerror());
+#define SYM(field, name)                                                  \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+  if (!g_rccl.field) return fail(LBM_ERR_COMM, "librccl lacks %s", name)
+  SYM(GetUniqueId, "ncclGetUniqueId");
+  SYM(CommInitRank, "ncclCommInitRank");
+  SYM(CommInitAll, "ncclCommInitAll");
+  SYM(CommDestroy, "ncclCommDestroy");
+  SYM(Send, "ncclSend");
+  SYM(Recv, "ncclRecv");
+  SYM(AllReduce, "ncclAllReduce");
+  SYM(GroupStart, "ncclGroupStart");
+  SYM(GroupEnd, "ncclGroupEnd");
+  SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  g_rccl.handle = h;
+  return LBM_OK;
+}
+
+#define NCCL_TRY(expr)                                                                          \
+  do {                                                                                          \
+    ncclResult_t r_ = (expr);                                                                   \
+    if (r_ != ncclSuccess)                                                                      \
+      return fail(LBM_ERR_COMM, "RCCL error during '%s' (%s:%d): %s", #expr, __FILE__, __LINE__, \
+                  g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?");                      \
+  } while (0)
+
+constexpr int kRing = 256;  // steps of per-workgroup partial sums buffered between reductions
+enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2 };
+
+struct Slab {
+  int dev = 0;
+  int index = 0;          // position in the global ring of slabs
+  int y0 = 0, rows = 0;   // global first row, rows held
+  int accel_row = -1;     // local index of global row ny-2, or -1
+  size_t plane_stride = 0;
+  float *cells[2] = {nullptr, nullptr};
+  uint8_t *mask = nullptr;
+  // halo buffers, 3*nx floats each: [parity][0 = south side, 1 = north side]
+  float *halo_send[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  float *halo_recv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  float *partials = nullptr;  // [kRing][nb_total]
+  int nb_main = 0, nb_edge = 0, nb_total = 0;
+  double *av_sum = nullptr;   // [capacity] per-step sum of |j|/rho over this slab's fluid cells
+  hipStream_t s_main = nullptr, s_edge = nullptr;
+  hipEvent_t ev_main[2] = {nullptr, nullptr};   // interior kernel of a step done
+  hipEvent_t ev_edgek[2] = {nullptr, nullptr};  // edge kernel of a step done (send buffers packed)
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;     // timing of lbm_run_timed
+  hipEvent_t ev_aux = nullptr;                     // cross-stream ordering inside a run
+  ncclComm_t comm = nullptr;
+  // output-stage scratch
+  float *fin_partials = nullptr;
+  int fin_blocks = 0;
+};
+
+}  // namespace
+
+struct lbm_ctx {
+  lbm_params p{};
+  std::vector<Slab> slabs;  // local slabs
+  int nslabs_global = 1;    // slabs in the ring (== slabs.size() unless rank mode)
+  bool rank_mode = false;
+  int rank = 0;
+  int cur = 0;              // index of the grid holding the current state
+  int steps_done = 0;
+  int ring_fill = 0;        // buffered steps not yet reduced
+  int transport = TRANSPORT_AUTO;
+  int transport_eff = TRANSPORT_COPY;
+  // options
+  int variant = 0;
+  int grid_blocks = 0;
+  int nt_stores = -1;
+  int use_graph = -1;
+  bool vec4 = true;
+  double *av_host = nullptr;  // staging for downloads
+};
+
+namespace {
+
+using namespace lbm;
+
+int div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+int set_dev(const Slab &s) {
+  HIP_TRY(hipSetDevice(s.dev));
+  return LBM_OK;
+}
+
+template <typename T>
+int dev_alloc(T **p, size_t count) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+  return LBM_OK;
+}
+
+// launch geometry of the step kernel for `work_rows` rows of a slab
+int step_blocks(const lbm_ctx *c, int work_rows) {
+  const int vec = c->vec4 ? 4 : 1;
+  const long threads = (long)(c->p.nx / vec) * work_rows;
+  int nb = div_up(threads, kBlock);
+  int cap = c->grid_blocks > 0 ? c->grid_blocks : 256 * 16;
+  nb = std::max(1, std::min(nb, cap));
+  return nb;
+}
+
+bool nt_effective(const lbm_ctx *c) {
+  if (c->nt_stores >= 0) return c->nt_stores != 0;
+  // both grids of a slab fit the 256 MiB Infinity Cache -> keep the written lines cacheable
+  const size_t grid_bytes = (size_t)9 * c->slabs[0].plane_stride * sizeof(float);
+  return 2 * grid_bytes > ((size_t)192 << 20);
+}
+
+void launch_step(const lbm_ctx *c, const StepArgs &a, int nblocks, hipStream_t st) {
+  const bool nt = nt_effective(c);
+  if (c->vec4) {
+    if (nt) hipLaunchKernelGGL((d2q9_step_direct<4, true>), dim3(nblocks), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((d2q9_step_direct<4, false>), dim3(nblocks), dim3(kBlock), 0, st, a);
+  } else {
+    if (nt) hipLaunchKernelGGL((d2q9_step_direct<1, true>), dim3(nblocks), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((d2q9_step_direct<1, false>), dim3(nblocks), dim3(kBlock), 0, st, a);
+  }
+}
+
+StepArgs base_args(const lbm_ctx *c, const Slab &s, int src, bool apply_accel) {
+  StepArgs a{};
+  a.src = s.cells[src];
+  a.dst = s.cells[src ^ 1];
+  a.mask = s.mask;
+  a.plane_stride = s.plane_stride;
+  a.nx = c->p.nx;
+  a.rows = s.rows;
+  a.accel_row = apply_accel ? s.accel_row : -1;
+  a.omega = c->p.omega;
+  a.aw1 = c->p.density * c->p.accel / 9.0f;
+  a.aw2 = c->p.density * c->p.accel / 36.0f;
+  return a;
+}
+
+// Move the packed edge rows of step parity q to the ring neighbours' receive buffers.
+int exchange_halos(lbm_ctx *c, int q) {
+  const size_t count = (size_t)3 * c->p.nx;
+  const int P = c->nslabs_global;
+  if (c->transport_eff == TRANSPORT_RCCL) {
+    NCCL_TRY(g_rccl.GroupStart());
+    for (Slab &s : c->slabs) {
+      const int north = (s.index + 1) % P, south = (s.index + P - 1) % P;
+      // my top row's planes 2,5,6 feed the north neighbour's south halo; my bottom row's 4,7,8 feed
+      // the south neighbour's north halo
+      NCCL_TRY(g_rccl.Send(s.halo_send[q][1], count, ncclFloat, north, s.comm, s.s_edge));
+      NCCL_TRY(g_rccl.Send(s.halo_send[q][0], count, ncclFloat, south, s.comm, s.s_edge));
+      NCCL_TRY(g_rccl.Recv(s.halo_recv[q][0], count, ncclFloat, south, s.comm, s.s_edge));
+      NCCL_TRY(g_rccl.Recv(s.halo_recv[q][1], count, ncclFloat, north, s.comm, s.s_edge));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+  } else {
+    // single process: each slab pulls from its neighbours once their edge kernels are done
+    for (Slab &s : c->slabs) {
+      if (set_dev(s)) return LBM_ERR_HIP;
+      Slab &north = c->slabs[(s.index + 1) % P];
+      Slab &south = c->slabs[(s.index + P - 1) % P];
+      HIP_TRY(hipStreamWaitEvent(s.s_edge, south.ev_edgek[q], 0));
+      HIP_TRY(hipStreamWaitEvent(s.s_edge, north.ev_edgek[q], 0));
+      HIP_TRY(hipMemcpyAsync(s.halo_recv[q][0], south.halo_send[q][1], count * sizeof(float), hipMemcpyDeviceToDevice, s.s_edge));
+      HIP_TRY(hipMemcpyAsync(s.halo_recv[q][1], north.halo_send[q][0], count * sizeof(float), hipMemcpyDeviceToDevice, s.s_edge));
+    }
+  }
+  return LBM_OK;
+}
+
+int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
+  if (nsteps < 0) return fail(LBM_ERR_ARG, "nsteps must be >= 0");
+  if (c->steps_done + nsteps > c->p.max_iters)
+    return fail(LBM_ERR_STATE, "av_vels record holds max_iters=%d steps; %d done, %d more requested", c->p.max_iters,
+                c->steps_done, nsteps);
+  if (timed && ms) *ms = 0.0;
+  if (nsteps == 0) return LBM_OK;
+  const bool multi = c->nslabs_global > 1;
+  const float aw1 = c->p.density * c->p.accel / 9.0f, aw2 = c->p.density * c->p.accel / 36.0f;
+  const int nx = c->p.nx;
+
+  // prologue: accelerate_flow of the first step on the current grid (kernels.cl:9-53); later
+  // steps get theirs fused into the previous step's write of row ny-2
+  for (Slab &s : c->slabs) {
+    if (set_dev(s)) return LBM_ERR_HIP;
+    if (multi) HIP_TRY(hipStreamSynchronize(s.s_edge));
+    if (s.accel_row >= 0) {
+      hipLaunchKernelGGL(accelerate_row, dim3(div_up(nx, 128)), dim3(128), 0, s.s_main, s.cells[c->cur], s.plane_stride,
+                         s.mask, nx, s.accel_row, aw1, aw2);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  if (multi) {
+    // halos of the initial state: pack the edge rows of the current grid and exchange them as if
+    // they were the result of step "-1" (parity 1)
+    for (Slab &s : c->slabs) {
+      if (set_dev(s)) return LBM_ERR_HIP;
+      hipLaunchKernelGGL(pack_halo_rows, dim3(div_up(nx, 128)), dim3(128), 0, s.s_main, s.cells[c->cur], s.plane_stride, nx,
+                         s.rows, s.halo_send[1][0], s.halo_send[1][1]);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(s.ev_main[1], s.s_main));
+      HIP_TRY(hipEventRecord(s.ev_edgek[1], s.s_main));
+      HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[1], 0));
+    }
+    if (int rc = exchange_halos(c, 1)) return rc;
+  }
+  if (timed)
+    for (Slab &s : c->slabs) {
+      if (set_dev(s)) return LBM_ERR_HIP;
+      if (multi) {
+        // start the clock on the main stream once the initial halos have landed
+        HIP_TRY(hipEventRecord(s.ev_aux, s.s_edge));
+        HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_aux, 0));
+      }
+      HIP_TRY(hipEventRecord(s.ev_t0, s.s_main));
+    }
+
+  int batch_first = c->steps_done;
+  for (int i = 0; i < nsteps; i++) {
+    const bool last = (i == nsteps - 1);
+    const int q = i & 1, qp = q ^ 1;  // parity of this step / of the previous one (initial state = 1)
+    const int src = c->cur;
+    if (!multi) {
+      Slab &s = c->slabs[0];
+      StepArgs a = base_args(c, s, src, !last);
+      for (int k = 0; k < 3; k++) {
+        static const int sp[3] = {2, 5, 6}, np[3] = {4, 7, 8};
+        a.south_src[k] = s.cells[src] + sp[k] * s.plane_stride + (size_t)(s.rows - 1) * nx;  // y wrap (kernels.cl:91-93)
+        a.north_src[k] = s.cells[src] + np[k] * s.plane_stride;
+      }
+      a.y_begin = 0; a.y_count = s.rows; a.y_step = 1;
+      a.partials = s.partials + (size_t)c->ring_fill * s.nb_total;
+      launch_step(c, a, s.nb_main, s.s_main);
+      HIP_TRY(hipGetLastError());
+    } else {
+      for (Slab &s : c->slabs) {
+        if (set_dev(s)) return LBM_ERR_HIP;
+        float *part = s.partials + (size_t)c->ring_fill * s.nb_total;
+        // edge rows 0 and rows-1: need the previous step's halos (edge stream order) and interior
+        HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
+        StepArgs e = base_args(c, s, src, !last);
+        for (int k = 0; k < 3; k++) {
+          e.south_src[k] = s.halo_recv[qp][0] + (size_t)k * nx;
+          e.north_src[k] = s.halo_recv[qp][1] + (size_t)k * nx;
+        }
+        e.send_south = s.halo_send[q][0];
+        e.send_north = s.halo_send[q][1];
+        e.y_begin = 0; e.y_count = 2; e.y_step = s.rows - 1;
+        e.partials = part + s.nb_main;
+        launch_step(c, e, s.nb_edge, s.s_edge);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s.ev_edgek[q], s.s_edge));
+        // interior rows 1..rows-2: need the previous step's edge rows
+        HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
+        if (s.rows > 2) {
+          StepArgs m = base_args(c, s, src, !last);
+          for (int k = 0; k < 3; k++) m.south_src[k] = m.north_src[k] = nullptr;  // never at a slab edge
+          m.y_begin = 1; m.y_count = s.rows - 2; m.y_step = 1;
+          m.partials = part;
+          launch_step(c, m, s.nb_main, s.s_main);
+          HIP_TRY(hipGetLastError());
+        } else {
+          HIP_TRY(hipMemsetAsync(part, 0, sizeof(float) * s.nb_main, s.s_main));
+        }
+        HIP_TRY(hipEventRecord(s.ev_main[q], s.s_main));
+      }
+      if (!last)
+        if (int rc = exchange_halos(c, q)) return rc;
+    }
+    c->cur ^= 1;
+    c->ring_fill++;
+    if (c->ring_fill == kRing || last) {
+      // flush_ring needs the parity of the last edge kernel
+      const int lastq = q;
+      const int fill = c->ring_fill;
+      for (Slab &s : c->slabs) {
+        if (set_dev(s)) return LBM_ERR_HIP;
+        if (multi) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[lastq], 0));
+        hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total,
+                           s.av_sum + batch_first);
+        HIP_TRY(hipGetLastError());
+        if (multi) {
+          // the next batch's edge kernels overwrite ring slots: order them after this reduction
+          HIP_TRY(hipEventRecord(s.ev_aux, s.s_main));
+          HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_aux, 0));
+        }
+      }
+      batch_first += fill;
+      c->ring_fill = 0;
+    }
+  }
+  c->steps_done += nsteps;
+
+  if (timed) {
+    float worst = 0.0f;
+    for (Slab &s : c->slabs) {
+      if (set_dev(s)) return LBM_ERR_HIP;
+      HIP_TRY(hipEventRecord(s.ev_t1, s.s_main));
+    }
+    for (Slab &s : c->slabs) {
+      if (set_dev(s)) return LBM_ERR_HIP;
+      HIP_TRY(hipEventSynchronize(s.ev_t1));
+      float t = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&t, s.ev_t0, s.ev_t1));
+      worst = std::max(worst, t);
+    }
+    if (ms) *ms = worst;
+  }
+  return LBM_OK;
+}
+
+int sync_all(lbm_ctx *c) {
+  for (Slab &s : c->slabs) {
+    if (set_dev(s)) return LBM_ERR_HIP;
+    if (s.s_edge) HIP_TRY(hipStreamSynchronize(s.s_edge));
+    HIP_TRY(hipStreamSynchronize(s.s_main));
+  }
+  return LBM_OK;
+}
+
+void free_slab(Slab &s) {
+  hipSetDevice(s.dev);
+  for (int i = 0; i < 2; i++) {
+    if (s.cells[i]) hipFree(s.cells[i]);
+    for (int j = 0; j < 2; j++) {
+      if (s.halo_send[i][j]) hipFree(s.halo_send[i][j]);
+      if (s.halo_recv[i][j]) hipFree(s.halo_recv[i][j]);
+    }
+    if (s.ev_main[i]) hipEventDestroy(s.ev_main[i]);
+    if (s.ev_edgek[i]) hipEventDestroy(s.ev_edgek[i]);
+  }
+  if (s.mask) hipFree(s.mask);
+  if (s.partials) hipFree(s.partials);
+  if (s.av_sum) hipFree(s.av_sum);
+  if (s.fin_partials) hipFree(s.fin_partials);
+  if (s.ev_t0) hipEventDestroy(s.ev_t0);
+  if (s.ev_t1) hipEventDestroy(s.ev_t1);
+  if (s.ev_aux) hipEventDestroy(s.ev_aux);
+  if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
+  if (s.s_edge) hipStreamDestroy(s.s_edge);
+  if (s.s_main) hipStreamDestroy(s.s_main);
+  s = Slab{};
+}
+
+int check_params(const lbm_params *p) {
+  if (!p) return fail(LBM_ERR_ARG, "params is NULL");
+  if (p->nx < 3 || p->ny < 3) return fail(LBM_ERR_ARG, "grid must be at least 3x3 (got %dx%d)", p->nx, p->ny);
+  if ((long)p->nx * p->ny > (1L << 31) - 1) return fail(LBM_ERR_ARG, "grid too large: %dx%d", p->nx, p->ny);
+  if (p->max_iters < 0) return fail(LBM_ERR_ARG, "max_iters must be >= 0");
+  return LBM_OK;
+}
+
+// Allocate and fill one slab (rows [y0, y0+rows) of the global grid).
+int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
+  const int nx = c->p.nx, ny = c->p.ny;
+  const bool multi = c->nslabs_global > 1;
+  if (set_dev(s)) return LBM_ERR_HIP;
+  HIP_TRY(hipStreamCreateWithFlags(&s.s_main, hipStreamNonBlocking));
+  if (multi) HIP_TRY(hipStreamCreateWithFlags(&s.s_edge, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(hipEventCreateWithFlags(&s.ev_main[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s.ev_edgek[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventCreate(&s.ev_t0));
+  HIP_TRY(hipEventCreate(&s.ev_t1));
+  HIP_TRY(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
+  const size_t n = (size_t)nx * s.rows;
+  // plane stride: whole 256-B lines plus one odd line so that the nine planes do not all start at
+  // the same offset of a power-of-two sized plane (HBM channel interleave)
+  s.plane_stride = ((n + 63) / 64) * 64 + 64 * 5;
+  for (int i = 0; i < 2; i++) {
+    if (dev_alloc(&s.cells[i], 9 * s.plane_stride)) return LBM_ERR_HIP;
+  }
+  if (dev_alloc(&s.mask, n + 64)) return LBM_ERR_HIP;
+  {
+    std::vector<uint8_t> m(n);
+    const int32_t *src = obstacles + (size_t)s.y0 * nx;
+    for (size_t i = 0; i < n; i++) m[i] = src[i] != 0;
+    HIP_TRY(hipMemcpy(s.mask, m.data(), n, hipMemcpyHostToDevice));
+  }
+  const int ar = ny - 2;  // kernels.cl:18
+  s.accel_row = (ar >= s.y0 && ar < s.y0 + s.rows) ? ar - s.y0 : -1;
+  if (multi) {
+    s.nb_main = step_blocks(c, std::max(1, s.rows - 2));
+    s.nb_edge = step_blocks(c, 2);
+    for (int q = 0; q < 2; q++)
+      for (int d = 0; d < 2; d++) {
+        if (dev_alloc(&s.halo_send[q][d], (size_t)3 * nx)) return LBM_ERR_HIP;
+        if (dev_alloc(&s.halo_recv[q][d], (size_t)3 * nx)) return LBM_ERR_HIP;
+      }
+  } else {
+    s.nb_main = step_blocks(c, s.rows);
+    s.nb_edge = 0;
+  }
+  s.nb_total = s.nb_main + s.nb_edge;
+  if (dev_alloc(&s.partials, (size_t)kRing * s.nb_total)) return LBM_ERR_HIP;
+  if (dev_alloc(&s.av_sum, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
+  s.fin_blocks = std::max(1, std::min(div_up((long)n, kBlock), 2048));
+  if (dev_alloc(&s.fin_partials, (size_t)s.fin_blocks)) return LBM_ERR_HIP;
+  return LBM_OK;
+}
+
+void split_rows(int ny, int P, int idx, int *y0, int *rows) {
+  const int base = ny / P, rem = ny % P;
+  *y0 = idx * base + std::min(idx, rem);
+  *rows = base + (idx < rem ? 1 : 0);
+}
+
+int rebuild_geometry(lbm_ctx *c) {
+  // grid_blocks / variant changes alter the number of partial sums per step
+  const bool multi = c->nslabs_global > 1;
+  for (Slab &s : c->slabs) {
+    if (set_dev(s)) return LBM_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(s.s_main));
+    if (multi) {
+      s.nb_main = step_blocks(c, std::max(1, s.rows - 2));
+      s.nb_edge = step_blocks(c, 2);
+    } else {
+      s.nb_main = step_blocks(c, s.rows);
+      s.nb_edge = 0;
+    }
+    s.nb_total = s.nb_main + s.nb_edge;
+    if (s.partials) HIP_TRY(hipFree(s.partials));
+    s.partials = nullptr;
+    if (dev_alloc(&s.partials, (size_t)kRing * s.nb_total)) return LBM_ERR_HIP;
+  }
+  return LBM_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *lbm_last_error(void) { return g_err.c_str(); }
+const char *lbm_version(void) { return "lbm-hip 0.1 (gfx950)"; }
+
+size_t lbm_comm_id_size(void) { return sizeof(ncclUniqueId); }
+
+int lbm_comm_get_id(void *comm_id_out) {
+  if (!comm_id_out) return fail(LBM_ERR_ARG, "comm_id_out is NULL");
+  if (int rc = load_rccl()) return rc;
+  ncclUniqueId id;
+  NCCL_TRY(g_rccl.GetUniqueId(&id));
+  memcpy(comm_id_out, &id, sizeof id);
+  return LBM_OK;
+}
+
+static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles, int nslabs_global,
+                         const std::vector<int> &slab_indices, const std::vector<int> &devs, bool rank_mode, int rank,
+                         const void *comm_id) {
+  if (!out) return fail(LBM_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (int rc = check_params(params)) return rc;
+  if (!obstacles) return fail(LBM_ERR_ARG, "obstacles is NULL");
+  if (nslabs_global < 1) return fail(LBM_ERR_ARG, "need at least one slab");
+  if (nslabs_global > 1 && params->ny / nslabs_global < 2)
+    return fail(LBM_ERR_ARG, "ny=%d gives fewer than 2 rows per slab over %d slabs", params->ny, nslabs_global);
+  int ndev_visible = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev_visible));
+  if (ndev_visible < 1) return fail(LBM_ERR_HIP, "no HIP device visible");
+  for (int d : devs)
+    if (d < 0 || d >= ndev_visible) return fail(LBM_ERR_ARG, "device index %d out of range (%d visible)", d, ndev_visible);
+
+  lbm_ctx *c = new lbm_ctx();
+  c->p = *params;
+  c->nslabs_global = nslabs_global;
+  c->rank_mode = rank_mode;
+  c->rank = rank;
+  c->vec4 = (params->nx % 4 == 0);
+  c->slabs.resize(slab_indices.size());
+  int rc = LBM_OK;
+  for (size_t i = 0; i < slab_indices.size() && rc == LBM_OK; i++) {
+    Slab &s = c->slabs[i];
+    s.dev = devs[i];
+    s.index = slab_indices[i];
+    split_rows(params->ny, nslabs_global, s.index, &s.y0, &s.rows);
+    rc = build_slab(c, s, obstacles);
+  }
+  // transport for halo exchange
+  if (rc == LBM_OK && nslabs_global > 1) {
+    bool dup = false;
+    for (size_t i = 0; i < devs.size(); i++)
+      for (size_t j = i + 1; j < devs.size(); j++) dup |= devs[i] == devs[j];
+    const char *env = getenv("LBM_TRANSPORT");
+    int want = TRANSPORT_AUTO;
+    if (env && !strcmp(env, "rccl")) want = TRANSPORT_RCCL;
+    if (env && !strcmp(env, "copy")) want = TRANSPORT_COPY;
+    if (rank_mode) c->transport_eff = TRANSPORT_RCCL;
+    else if (want == TRANSPORT_AUTO) c->transport_eff = dup ? TRANSPORT_COPY : TRANSPORT_RCCL;
+    else c->transport_eff = want;
+    if (c->transport_eff == TRANSPORT_RCCL && !rank_mode && dup) {
+      rc = fail(LBM_ERR_ARG, "RCCL transport needs distinct devices per slab");
+    } else if (c->transport_eff == TRANSPORT_RCCL) {
+      rc = load_rccl();
+      if (rc == LBM_OK) {
+        if (rank_mode) {
+          ncclUniqueId id;
+          memcpy(&id, comm_id, sizeof id);
+          hipSetDevice(c->slabs[0].dev);
+          ncclResult_t r = g_rccl.CommInitRank(&c->slabs[0].comm, nslabs_global, id, rank);
+          if (r != ncclSuccess) rc = fail(LBM_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+        } else {
+          std::vector<ncclComm_t> comms(devs.size());
+          ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+          if (r != ncclSuccess) rc = fail(LBM_ERR_COMM, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
+          else
+            for (size_t i = 0; i < devs.size(); i++) c->slabs[i].comm = comms[i];
+        }
+      }
+    } else {
+      // device-to-device copies: enable peer access between distinct devices
+      for (size_t i = 0; i < devs.size(); i++)
+        for (size_t j = 0; j < devs.size(); j++)
+          if (devs[i] != devs[j]) {
+            hipSetDevice(devs[i]);
+            hipError_t e = hipDeviceEnablePeerAccess(devs[j], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+          }
+    }
+  }
+  if (rc == LBM_OK) {
+    c->av_host = (double *)malloc(sizeof(double) * (size_t)std::max(1, params->max_iters));
+    if (!c->av_host) rc = fail(LBM_ERR_ARG, "out of host memory");
+  }
+  if (rc != LBM_OK) {
+    std::string keep = g_err;
+    lbm_destroy(c);
+    g_err = keep;
+    return rc;
+  }
+  *out = c;
+  // default initial state: uniform rest state on the device
+  return lbm_upload(c, nullptr);
+}
+
+int lbm_create(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles, int ndev, const int *dev_ids) {
+  std::vector<int> idx, devs;
+  if (ndev <= 1 && dev_ids == nullptr) {
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    idx.push_back(0);
+    devs.push_back(cur);
+    ndev = 1;
+  } else {
+    if (ndev < 1 || !dev_ids) return fail(LBM_ERR_ARG, "ndev=%d needs dev_ids", ndev);
+    for (int i = 0; i < ndev; i++) {
+      idx.push_back(i);
+      devs.push_back(dev_ids[i]);
+    }
+  }
+  return create_common(out, params, obstacles, ndev, idx, devs, false, 0, nullptr);
+}
+
+int lbm_create_rank(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles, int rank, int nranks, int device,
+                    const void *comm_id) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(LBM_ERR_ARG, "bad rank %d of %d", rank, nranks);
+  if (nranks > 1 && !comm_id) return fail(LBM_ERR_ARG, "comm_id is NULL");
+  std::vector<int> idx{rank}, devs{device};
+  return create_common(out, params, obstacles, nranks, idx, devs, nranks > 1, rank, comm_id);
+}
+
+int lbm_upload(lbm_ctx *c, const float *cells) {
+  if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
+  if (int rc = sync_all(c)) return rc;
+  const int nx = c->p.nx, ny = c->p.ny;
+  const size_t n_global = (size_t)nx * ny;
+  for (Slab &s : c->slabs) {
+    if (set_dev(s)) return LBM_ERR_HIP;
+    const size_t n = (size_t)nx * s.rows;
+    if (cells) {
+      for (int k = 0; k < 9; k++)
+        HIP_TRY(hipMemcpyAsync(s.cells[0] + k * s.plane_stride, cells + k * n_global + (size_t)s.y0 * nx, n * sizeof(float),
+                               hipMemcpyHostToDevice, s.s_main));
+    } else {
+      // d2q9-bgk.c:529-531
+      const float w0 = c->p.density * 4.0f / 9.0f, w1 = c->p.density / 9.0f, w2 = c->p.density / 36.0f;
+      hipLaunchKernelGGL(init_cells, dim3(std::min(div_up((long)n, 256), 4096)), dim3(256), 0, s.s_main, s.cells[0],
+                         s.plane_stride, n, w0, w1, w2);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s.s_main));
+  }
+  c->cur = 0;
+  c->steps_done = 0;
+  c->ring_fill = 0;
+  return LBM_OK;
+}
+
+int lbm_run(lbm_ctx *c, int nsteps) {
+  if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
+  return run_steps(c, nsteps, false, nullptr);
+}
+
+int lbm_run_timed(lbm_ctx *c, int nsteps, double *ms) {
+  if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
+  return run_steps(c, nsteps, true, ms);
+}
+
+int lbm_sync(lbm_ctx *c) {
+  if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
+  return sync_all(c);
+}
+
+int lbm_steps_done(const lbm_ctx *c) { return c ? c->steps_done : -1; }
+
+int lbm_row_range(const lbm_ctx *c, int *y0, int *y1) {
+  if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
+  int lo = c->p.ny, hi = 0;
+  for (const Slab &s : c->slabs) {
+    lo = std::min(lo, s.y0);
+    hi = std::max(hi, s.y0 + s.rows);
+  }
+  if (y0) *y0 = lo;
+  if (y1) *y1 = hi;
+  return LBM_OK;
+}
+
+int lbm_download(lbm_ctx *c, float *cells_out, float *av_vels_out) {
+  if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
+  if (int rc = sync_all(c)) return rc;
+  const int nx = c->p.nx, ny = c->p.ny;
+  const size_t n_global = (size_t)nx * ny;
+  if (cells_out) {
+    for (Slab &s : c->slabs) {
+      if (set_dev(s)) return LBM_ERR_HIP;
+      const size_t n = (size_t)nx * s.rows;
+      for (int k = 0; k < 9; k++)
+        HIP_TRY(hipMemcpyAsync(cells_out + k * n_global + (size_t)s.y0 * nx, s.cells[c->cur] + k * s.plane_stride,
+                               n * sizeof(float), hipMemcpyDeviceToHost, s.s_main));
+      HIP_TRY(hipStreamSynchronize(s.s_main));
+    }
+  }
+  if (av_vels_out && c->steps_done > 0) {
+    const int T = c->steps_done;
+    std::vector<double> total(T, 0.0);
+    if (c->rank_mode && c->nslabs_global > 1) {
+      // combine the per-rank velocity sums: one all-reduce over the whole record
+      Slab &s = c->slabs[0];
+      if (set_dev(s)) return LBM_ERR_HIP;
+      double *tmp = nullptr;
+      if (dev_alloc(&tmp, (size_t)T)) return LBM_ERR_HIP;
+      ncclResult_t r = g_rccl.AllReduce(s.av_sum, tmp, (size_t)T, ncclDouble, ncclSum, s.comm, s.s_main);
+      if (r != ncclSuccess) {
+        hipFree(tmp);
+        return fail(LBM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
+      }
+      hipError_t e = hipMemcpyAsync(total.data(), tmp, sizeof(double) * T, hipMemcpyDeviceToHost, s.s_main);
+      if (e == hipSuccess) e = hipStreamSynchronize(s.s_main);
+      hipFree(tmp);
+      if (e != hipSuccess) return fail(LBM_ERR_HIP, "HIP error reading av_vels: %s", hipGetErrorString(e));
+    } else {
+      for (Slab &s : c->slabs) {
+        if (set_dev(s)) return LBM_ERR_HIP;
+        HIP_TRY(hipMemcpy(c->av_host, s.av_sum, sizeof(double) * T, hipMemcpyDeviceToHost));
+        for (int t = 0; t < T; t++) total[t] += c->av_host[t];
+      }
+    }
+    // kernels.cl:202: sum * FREE_CELLS_INV
+    for (int t = 0; t < T; t++) av_vels_out[t] = (float)(total[t] * (double)c->p.free_cells_inv);
+  }
+  return LBM_OK;
+}
+
+int lbm_final_state(lbm_ctx *c, float *u_x, float *u_y, float *u, float *pressure) {
+  if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
+  if (int rc = sync_all(c)) return rc;
+  const int nx = c->p.nx;
+  float *outs[4] = {u_x, u_y, u, pressure};
+  for (Slab &s : c->slabs) {
+    if (set_dev(s)) return LBM_ERR_HIP;
+    const size_t n = (size_t)nx * s.rows;
+    float *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; i++)
+      if (outs[i] && dev_alloc(&d[i], n)) return LBM_ERR_HIP;
+    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.cells[c->cur], s.plane_stride, s.mask,
+                       n, c->p.density, d[0], d[1], d[2], d[3], s.fin_partials);
+    hipError_t e = hipGetLastError();
+    for (int i = 0; i < 4 && e == hipSuccess; i++)
+      if (outs[i]) e = hipMemcpyAsync(outs[i] + (size_t)s.y0 * nx, d[i], n * sizeof(float), hipMemcpyDeviceToHost, s.s_main);
+    if (e == hipSuccess) e = hipStreamSynchronize(s.s_main);
+    for (int i = 0; i < 4; i++)
+      if (d[i]) hipFree(d[i]);
+    if (e != hipSuccess) return fail(LBM_ERR_HIP, "HIP error in output stage: %s", hipGetErrorString(e));
+  }
+  return LBM_OK;
+}
+
+int lbm_reynolds(lbm_ctx *c, float *reynolds_out) {
+  if (!c || !reynolds_out) return fail(LBM_ERR_ARG, "NULL argument");
+  if (int rc = sync_all(c)) return rc;
+  double tot = 0.0;
+  for (Slab &s : c->slabs) {
+    if (set_dev(s)) return LBM_ERR_HIP;
+    const size_t n = (size_t)c->p.nx * s.rows;
+    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.cells[c->cur], s.plane_stride, s.mask,
+                       n, c->p.density, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr,
+                       s.fin_partials);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> part(s.fin_blocks);
+    HIP_TRY(hipMemcpyAsync(part.data(), s.fin_partials, sizeof(float) * s.fin_blocks, hipMemcpyDeviceToHost, s.s_main));
+    HIP_TRY(hipStreamSynchronize(s.s_main));
+    for (float v : part) tot += v;
+  }
+  if (c->rank_mode && c->nslabs_global > 1) {
+    Slab &s = c->slabs[0];
+    double *tmp = nullptr;
+    if (dev_alloc(&tmp, 2)) return LBM_ERR_HIP;
+    hipError_t e = hipMemcpy(tmp, &tot, sizeof(double), hipMemcpyHostToDevice);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = g_rccl.AllReduce(tmp, tmp + 1, 1, ncclDouble, ncclSum, s.comm, s.s_main);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(s.s_main);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpy(&tot, tmp + 1, sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    if (r != ncclSuccess) return fail(LBM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
+    if (e != hipSuccess) return fail(LBM_ERR_HIP, "HIP error in reynolds: %s", hipGetErrorString(e));
+  }
+  // d2q9-bgk.c:747-752
+  const float viscosity = 1.0f / 6.0f * (2.0f / c->p.omega - 1.0f);
+  const float av = (float)(tot * (double)c->p.free_cells_inv);
+  *reynolds_out = av * c->p.reynolds_dim / viscosity;
+  return LBM_OK;
+}
+
+int lbm_set_option(lbm_ctx *c, const char *key, long value) {
+  if (!c || !key) return fail(LBM_ERR_ARG, "NULL argument");
+  if (!strcmp(key, "variant")) {
+    if (value < 0 || value > 3) return fail(LBM_ERR_ARG, "variant must be 0..3");
+    c->variant = (int)value;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "grid_blocks")) {
+    if (value < 0) return fail(LBM_ERR_ARG, "grid_blocks must be >= 0");
+    if (int rc = sync_all(c)) return rc;
+    c->grid_blocks = (int)value;
+    return rebuild_geometry(c);
+  }
+  if (!strcmp(key, "nt_stores")) { c->nt_stores = (int)value; return LBM_OK; }
+  if (!strcmp(key, "use_graph")) { c->use_graph = (int)value; return LBM_OK; }
+  if (!strcmp(key, "transport")) { c->transport = (int)value; return LBM_OK; }
+  return fail(LBM_ERR_ARG, "unknown option '%s'", key);
+}
+
+int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
+  if (!c || !key || !value) return fail(LBM_ERR_ARG, "NULL argument");
+  if (!strcmp(key, "variant")) *value = c->variant;
+  else if (!strcmp(key, "grid_blocks")) *value = c->slabs.empty() ? 0 : c->slabs[0].nb_main;
+  else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
+  else if (!strcmp(key, "use_graph")) *value = c->use_graph;
+  else if (!strcmp(key, "transport")) *value = c->transport_eff;
+  else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;
+  else return fail(LBM_ERR_ARG, "unknown option '%s'", key);
+  return LBM_OK;
+}
+
+int lbm_copy_bandwidth(size_t bytes, int iters, double *gbps) {
+  if (!gbps || iters < 1 || bytes < 16) return fail(LBM_ERR_ARG, "bad argument");
+  const size_t n = bytes / 16;
+  float4 *a = nullptr, *b = nullptr;
+  HIP_TRY(hipMalloc((void **)&a, n * 16));
+  hipError_t e = hipMalloc((void **)&b, n * 16);
+  if (e != hipSuccess) {
+    hipFree(a);
+    return fail(LBM_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+  }
+  hipEvent_t t0, t1;
+  hipEventCreate(&t0);
+  hipEventCreate(&t1);
+  hipMemset(a, 1, n * 16);
+  const int nb = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 256 * 16);
+  hipLaunchKernelGGL(lbm::copy_f4, dim3(nb), dim3(kBlock), 0, 0, a, b, n);  // warm-up
+  hipEventRecord(t0, 0);
+  for (int i = 0; i < iters; i++) {
+    if (i & 1) hipLaunchKernelGGL(lbm::copy_f4, dim3(nb), dim3(kBlock), 0, 0, b, a, n);
+    else hipLaunchKernelGGL(lbm::copy_f4, dim3(nb), dim3(kBlock), 0, 0, a, b, n);
+  }
+  hipEventRecord(t1, 0);
+  e = hipEventSynchronize(t1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, t0, t1);
+  hipEventDestroy(t0);
+  hipEventDestroy(t1);
+  hipFree(a);
+  hipFree(b);
+  if (e != hipSuccess) return fail(LBM_ERR_HIP, "copy kernel: %s", hipGetErrorString(e));
+  *gbps = 2.0 * (double)(n * 16) * iters / (ms * 1e-3) / 1e9;
+  return LBM_OK;
+}
+
+void lbm_destroy(lbm_ctx *c) {
+  if (!c) return;
+  for (Slab &s : c->slabs) {
+    hipSetDevice(s.dev);
+    if (s.s_main) hipStreamSynchronize(s.s_main);
+    if (s.s_edge) hipStreamSynchronize(s.s_edge);
+  }
+  for (Slab &s : c->slabs) free_slab(s);
+  free(c->av_host);
+  delete c;
+}
+
+}  // extern "C"

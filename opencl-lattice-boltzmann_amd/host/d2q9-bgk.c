@@ -1,0 +1,317 @@
+/*
+ * d2q9-bgk — thin C host for the MI355X-native D2Q9-BGK lattice-Boltzmann timestep.
+ *
+ * Keeps the process contract of the reference's d2q9-bgk.c (ag14774/OpenCL-Lattice-Boltzmann):
+ *   usage          d2q9-bgk <paramfile> <obstaclefile>                 (d2q9-bgk.c:183-191,876-880)
+ *   inputs         7-token parameter file, "x y 1" obstacle lines      (d2q9-bgk.c:466-492,571-586)
+ *   errors         "Error at line N of file F:\n<message>\n", exit 1   (d2q9-bgk.c:868-874)
+ *   outputs        final_state.dat and av_vels.dat in the CWD          (d2q9-bgk.c:69-70,772-856)
+ *   stdout         ==done== / Reynolds number / three elapsed times    (d2q9-bgk.c:271-275)
+ *   timed region   initial-state transfer + step loop + read-back      (d2q9-bgk.c:196-263)
+ * All device work goes through the C ABI of liblbm_hip.so (include/lbm.h); this file contains no
+ * GPU code and no numerics of the timestep.  The two input files are mmap'ed and scanned in place.
+ *
+ * Environment (extensions; none is needed for a reference-style run):
+ *   LBM_NGPUS=n | LBM_DEVICES=a,b,..  row-partition the grid over several GPUs (one process)
+ *   LBM_MAX_ITERS=n                   override maxIters (benchmark runs on large grids)
+ *   LBM_NO_OUTPUT=1                   skip writing the two .dat files
+ *   LBM_HOST_INIT=1                   build the initial state on the host and upload it, as the
+ *                                     reference does (default: initialise on the device)
+ */
+#include <errno.h>
+#include <fcntl.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/resource.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include "lbm.h"
+
+#define NSPEEDS 9
+#define FINALSTATEFILE "final_state.dat"
+#define AVVELSFILE "av_vels.dat"
+
+static void die(const char *message, const int line, const char *file)
+{
+  fprintf(stderr, "Error at line %d of file %s:\n", line, file);
+  fprintf(stderr, "%s\n", message);
+  fflush(stderr);
+  exit(EXIT_FAILURE);
+}
+
+static void usage(const char *exe)
+{
+  fprintf(stderr, "Usage: %s <paramfile> <obstaclefile>\n", exe);
+  exit(EXIT_FAILURE);
+}
+
+/* like the reference's checkError (d2q9-bgk.c:858-866), for the C ABI */
+static void check_lbm(int rc, const char *op, const int line)
+{
+  if (rc != LBM_OK) {
+    fprintf(stderr, "LBM error during '%s' on line %d: %d (%s)\n", op, line, rc, lbm_last_error());
+    fflush(stderr);
+    exit(EXIT_FAILURE);
+  }
+}
+
+/* ---- mmap'ed text scanning ------------------------------------------------------------------ */
+
+typedef struct { const char *base, *cur, *end; size_t len; } text_t;
+
+static int map_file(const char *path, text_t *t)
+{
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return -1;
+  struct stat st;
+  if (fstat(fd, &st) != 0) { close(fd); return -1; }
+  t->len = (size_t)st.st_size;
+  t->base = NULL;
+  if (t->len > 0) {
+    void *p = mmap(NULL, t->len, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (p == MAP_FAILED) { close(fd); return -1; }
+    t->base = (const char *)p;
+  }
+  close(fd);
+  t->cur = t->base;
+  t->end = t->base + t->len;
+  return 0;
+}
+
+static void unmap_file(text_t *t)
+{
+  if (t->base) munmap((void *)t->base, t->len);
+}
+
+static void skip_space(text_t *t)
+{
+  while (t->cur < t->end && (*t->cur == ' ' || (*t->cur >= '\t' && *t->cur <= '\r'))) t->cur++;
+}
+
+/* scanf("%d") on the mapped text: 1 converted, 0 matching failure, EOF at end of input */
+static int scan_int(text_t *t, int *out)
+{
+  skip_space(t);
+  if (t->cur >= t->end) return EOF;
+  const char *p = t->cur;
+  int neg = 0;
+  if (*p == '+' || *p == '-') { neg = (*p == '-'); p++; }
+  if (p >= t->end || *p < '0' || *p > '9') return 0;
+  long v = 0;
+  while (p < t->end && *p >= '0' && *p <= '9') {
+    if (v < (1L << 40)) v = v * 10 + (*p - '0');
+    p++;
+  }
+  *out = (int)(neg ? -v : v);
+  t->cur = p;
+  return 1;
+}
+
+/* scanf("%f") on the mapped text */
+static int scan_float(text_t *t, float *out)
+{
+  skip_space(t);
+  if (t->cur >= t->end) return EOF;
+  char buf[64];
+  size_t n = 0;
+  const char *p = t->cur;
+  while (p < t->end && n < sizeof(buf) - 1 && !(*p == ' ' || (*p >= '\t' && *p <= '\r'))) buf[n++] = *p++;
+  buf[n] = '\0';
+  char *endp = NULL;
+  errno = 0;
+  float v = strtof(buf, &endp);
+  if (endp == buf) return 0;
+  *out = v;
+  t->cur += (endp - buf);
+  return 1;
+}
+
+/* ---- input stage: d2q9-bgk.c:444-597 --------------------------------------------------------- */
+
+static void load_params(const char *paramfile, lbm_params *params)
+{
+  char message[1024];
+  text_t t;
+  if (map_file(paramfile, &t) != 0) {
+    snprintf(message, sizeof message, "could not open input parameter file: %s", paramfile);
+    die(message, __LINE__, __FILE__);
+  }
+  if (scan_int(&t, &params->nx) != 1) die("could not read param file: nx", __LINE__, __FILE__);
+  if (scan_int(&t, &params->ny) != 1) die("could not read param file: ny", __LINE__, __FILE__);
+  if (scan_int(&t, &params->max_iters) != 1) die("could not read param file: maxIters", __LINE__, __FILE__);
+  if (scan_int(&t, &params->reynolds_dim) != 1) die("could not read param file: reynolds_dim", __LINE__, __FILE__);
+  if (scan_float(&t, &params->density) != 1) die("could not read param file: density", __LINE__, __FILE__);
+  if (scan_float(&t, &params->accel) != 1) die("could not read param file: accel", __LINE__, __FILE__);
+  if (scan_float(&t, &params->omega) != 1) die("could not read param file: omega", __LINE__, __FILE__);
+  unmap_file(&t);
+}
+
+static void load_obstacles(const char *obstaclefile, lbm_params *params, int32_t *obstacles)
+{
+  char message[1024];
+  text_t t;
+  if (map_file(obstaclefile, &t) != 0) {
+    snprintf(message, sizeof message, "could not open input obstacles file: %s", obstaclefile);
+    die(message, __LINE__, __FILE__);
+  }
+  long free_cells = (long)params->nx * params->ny;
+  for (;;) {
+    int xx = 0, yy = 0, blocked = 0;
+    /* fscanf("%d %d %d\n"): EOF only when the input ends before the first conversion */
+    int r0 = scan_int(&t, &xx);
+    if (r0 == EOF) break;
+    int retval = r0;
+    if (retval == 1) {
+      int r1 = scan_int(&t, &yy);
+      if (r1 == 1) {
+        retval = 2;
+        if (scan_int(&t, &blocked) == 1) retval = 3;
+      }
+    }
+    /* some checks, d2q9-bgk.c:573-580 */
+    if (retval != 3) die("expected 3 values per line in obstacle file", __LINE__, __FILE__);
+    if (xx < 0 || xx > params->nx - 1) die("obstacle x-coord out of range", __LINE__, __FILE__);
+    if (yy < 0 || yy > params->ny - 1) die("obstacle y-coord out of range", __LINE__, __FILE__);
+    if (blocked != 1) die("obstacle blocked value should be 1", __LINE__, __FILE__);
+    /* a cell listed twice is one blocked cell, d2q9-bgk.c:583-585 */
+    if (!obstacles[(size_t)yy * params->nx + xx]) free_cells--;
+    obstacles[(size_t)yy * params->nx + xx] = blocked;
+  }
+  unmap_file(&t);
+  params->free_cells_inv = 1.0f / free_cells;
+}
+
+/* ---- output stage: d2q9-bgk.c:772-856 ---------------------------------------------------------- */
+
+static int write_values(const lbm_params *params, const float *u_x, const float *u_y, const float *u,
+                        const float *pressure, const int32_t *obstacles, const float *av_vels)
+{
+  FILE *fp = fopen(FINALSTATEFILE, "w");
+  if (fp == NULL) die("could not open file output file", __LINE__, __FILE__);
+  static char iobuf[1 << 20];
+  setvbuf(fp, iobuf, _IOFBF, sizeof iobuf);
+  for (int ii = 0; ii < params->ny; ii++) {
+    for (int jj = 0; jj < params->nx; jj++) {
+      const size_t c = (size_t)ii * params->nx + jj;
+      fprintf(fp, "%d %d %.12E %.12E %.12E %.12E %d\n", jj, ii, u_x[c], u_y[c], u[c], pressure[c], obstacles[c]);
+    }
+  }
+  fclose(fp);
+
+  fp = fopen(AVVELSFILE, "w");
+  if (fp == NULL) die("could not open file output file", __LINE__, __FILE__);
+  for (int ii = 0; ii < params->max_iters; ii++) fprintf(fp, "%d:\t%.12E\n", ii, av_vels[ii]);
+  fclose(fp);
+  return EXIT_SUCCESS;
+}
+
+static int parse_devices(int *devs, int max)
+{
+  const char *list = getenv("LBM_DEVICES");
+  int n = 0;
+  if (list && *list) {
+    char *copy = strdup(list);
+    for (char *tok = strtok(copy, ","); tok && n < max; tok = strtok(NULL, ",")) devs[n++] = atoi(tok);
+    free(copy);
+    return n;
+  }
+  const char *ng = getenv("LBM_NGPUS");
+  if (ng && atoi(ng) > 1) {
+    n = atoi(ng) < max ? atoi(ng) : max;
+    for (int i = 0; i < n; i++) devs[i] = i;
+  }
+  return n;
+}
+
+int main(int argc, char *argv[])
+{
+  if (argc != 3) usage(argv[0]);
+  const char *paramfile = argv[1];
+  const char *obstaclefile = argv[2];
+
+  /* initialise: parameters, obstacle map, context (d2q9-bgk.c:194) */
+  lbm_params params;
+  memset(&params, 0, sizeof params);
+  load_params(paramfile, &params);
+  if (getenv("LBM_MAX_ITERS")) params.max_iters = atoi(getenv("LBM_MAX_ITERS"));
+  const size_t ncells = (size_t)params.nx * params.ny;
+  int32_t *obstacles = (int32_t *)calloc(ncells, sizeof(int32_t));
+  if (obstacles == NULL) die("cannot allocate column memory for obstacles", __LINE__, __FILE__);
+  load_obstacles(obstaclefile, &params, obstacles);
+  float *av_vels = (float *)malloc(sizeof(float) * (size_t)(params.max_iters > 0 ? params.max_iters : 1));
+  if (av_vels == NULL) die("cannot allocate memory for av_vels", __LINE__, __FILE__);
+
+  int devs[64];
+  const int ndev = parse_devices(devs, 64);
+  lbm_ctx *ctx = NULL;
+  check_lbm(lbm_create(&ctx, &params, obstacles, ndev > 0 ? ndev : 1, ndev > 0 ? devs : NULL), "creating context", __LINE__);
+
+  float *cells = NULL;
+  if (getenv("LBM_HOST_INIT")) {
+    /* d2q9-bgk.c:519-550 */
+    cells = (float *)malloc(sizeof(float) * NSPEEDS * ncells);
+    if (cells == NULL) die("cannot allocate memory for cells", __LINE__, __FILE__);
+    const float w0 = params.density * 4.0f / 9.0f, w1 = params.density / 9.0f, w2 = params.density / 36.0f;
+    for (size_t i = 0; i < ncells; i++) {
+      cells[i] = w0;
+      for (int k = 1; k <= 4; k++) cells[k * ncells + i] = w1;
+      for (int k = 5; k <= 8; k++) cells[k * ncells + i] = w2;
+    }
+  }
+
+  struct timeval timstr;
+  struct rusage ru;
+  gettimeofday(&timstr, NULL);
+  const double tic = timstr.tv_sec + (timstr.tv_usec / 1000000.0);
+
+  check_lbm(lbm_upload(ctx, cells), "writing cells data", __LINE__);
+  double loop_ms = 0.0;
+  check_lbm(lbm_run_timed(ctx, params.max_iters, &loop_ms), "running timesteps", __LINE__);
+  check_lbm(lbm_sync(ctx), "waiting for queue", __LINE__);
+  check_lbm(lbm_download(ctx, NULL, av_vels), "reading av_vels data", __LINE__);
+  /* the reference reads the whole 9-plane state back and derives the output columns on the host
+   * (d2q9-bgk.c:251-253,787-832); here the device computes the four columns and only those move */
+  float *fields = (float *)malloc(sizeof(float) * 4 * ncells);
+  if (fields == NULL) die("cannot allocate memory for output fields", __LINE__, __FILE__);
+  check_lbm(lbm_final_state(ctx, fields, fields + ncells, fields + 2 * ncells, fields + 3 * ncells),
+            "reading cells data", __LINE__);
+  float reynolds = 0.0f;
+  check_lbm(lbm_reynolds(ctx, &reynolds), "computing reynolds number", __LINE__);
+
+  gettimeofday(&timstr, NULL);
+  const double toc = timstr.tv_sec + (timstr.tv_usec / 1000000.0);
+  getrusage(RUSAGE_SELF, &ru);
+  const double usrtim = ru.ru_utime.tv_sec + (ru.ru_utime.tv_usec / 1000000.0);
+  const double systim = ru.ru_stime.tv_sec + (ru.ru_stime.tv_usec / 1000000.0);
+
+  /* d2q9-bgk.c:271-275 */
+  printf("==done==\n");
+  printf("Reynolds number:\t\t%.12E\n", reynolds);
+  printf("Elapsed time:\t\t\t%.6lf (s)\n", toc - tic);
+  printf("Elapsed user CPU time:\t\t%.6lf (s)\n", usrtim);
+  printf("Elapsed system CPU time:\t%.6lf (s)\n", systim);
+  /* extra labelled lines (not in the reference) */
+  const double lu = (double)ncells * params.max_iters;
+  if (params.max_iters > 0 && loop_ms > 0.0) {
+    printf("Step loop time:\t\t\t%.6lf (s)\n", loop_ms * 1e-3);
+    printf("MLUPS (step loop):\t\t%.1f\n", lu / (loop_ms * 1e-3) / 1e6);
+    printf("MLUPS (elapsed time):\t\t%.1f\n", lu / (toc - tic) / 1e6);
+    printf("HBM GB/s (72 B/LU, loop):\t%.1f\n", 72.0 * lu / (loop_ms * 1e-3) / 1e9);
+  }
+  if (!getenv("LBM_NO_OUTPUT"))
+    write_values(&params, fields, fields + ncells, fields + 2 * ncells, fields + 3 * ncells, obstacles, av_vels);
+
+  /* finalise (d2q9-bgk.c:715-744) */
+  lbm_destroy(ctx);
+  free(fields);
+  free(cells);
+  free(obstacles);
+  free(av_vels);
+  return EXIT_SUCCESS;
+}

@@ -29,6 +29,9 @@ class Oracle:
         path = os.path.join(HERE, name)
         if not os.path.exists(path):
             build()
+        if omp and "OMP_NUM_THREADS" not in os.environ:
+            # a container may expose far more hardware threads than its CPU share
+            os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, len(os.sched_getaffinity(0)))))
         self.lib = ctypes.CDLL(path)
         self.real = np.float32 if precision == "f32" else np.float64
         creal = ctypes.c_float if precision == "f32" else ctypes.c_double
