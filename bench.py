@@ -1,2 +1,214 @@
 #!/usr/bin/env python3
-"""placeholder - replaced below"""
+"""bench.py — MLUPS and fraction of the HBM roofline of the D2Q9-BGK timestep on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one lattice-Boltzmann timestep (accelerate_flow + stream + collide + av_vels
+reduction, the reference's loop body d2q9-bgk.c:221-238) over the whole grid.  Workload: the
+synthetic 8192x8192 lid-driven cavity of BASELINE.json (only the four border lines blocked),
+uniform rest initial state, fp32.  With N > 1 the grid is row-partitioned over N ranks (one
+process per GPU), halos go by RCCL send/recv inside liblbm_hip.so, the velocity sums by an RCCL
+all-reduce; the RCCL id is distributed with torch.distributed.  Prints ONE JSON line on rank 0.
+
+Algorithmic traffic: 72 B per lattice update (9 fp32 loads + 9 fp32 stores, kernels.cl:104-112,
+189-197); one launch of the step kernel updates every cell of the rank's slab once.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_LU = 72.0
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cavity(nx, ny):
+    ob = np.zeros((ny, nx), dtype=np.int32)
+    ob[0, :] = ob[-1, :] = 1
+    ob[:, 0] = ob[:, -1] = 1
+    return ob
+
+
+def make_workload(name, nx, ny):
+    if name == "cavity":
+        return cavity(nx, ny)
+    if name == "empty":
+        return np.zeros((ny, nx), dtype=np.int32)
+    if name == "tiled":
+        import lbm_amd
+        _, ob = lbm_amd.read_inputs(os.path.join(ROOT, "inputs", "input_1024x1024.params"),
+                                    os.path.join(ROOT, "inputs", "obstacles_1024x1024.dat"))
+        assert nx % 1024 == 0 and ny % 1024 == 0
+        return np.tile(ob, (ny // 1024, nx // 1024))
+    raise ValueError(name)
+
+
+def cpu_baseline(nx, ny, obstacles, accel, budget_s=15.0):
+    """Serial fp32 oracle (the CPU restatement of the reference's timestep) on the host cores of
+    this box: a bounded number of timesteps of the same grid, 1 thread."""
+    from oracle.oracle import Oracle
+    orc = Oracle("f32")
+    p = orc.make_params(nx, ny, 1, 10, 0.1, accel, 1.85)
+    orc.set_obstacles(p, obstacles)
+    src = orc.init_cells(p)
+    dst = np.empty_like(src)
+    # one untimed step for page faults, then as many as fit the budget (at least 2)
+    orc.accelerate_flow(p, src, obstacles)
+    orc.timestep(p, src, dst, obstacles)
+    src, dst = dst, src
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.accelerate_flow(p, src, obstacles)
+        orc.timestep(p, src, dst, obstacles)
+        src, dst = dst, src
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 2 and (el > budget_s or n >= 64):
+            break
+    return {"value": round(nx * ny * n / el / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "port",
+            "sample": "%d timesteps of the same %dx%d grid with the serial fp32 oracle "
+                      "(oracle/d2q9_oracle.c, gcc -O3 -march=native, 1 of %d host cores)" % (n, nx, ny, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--nx", type=int, default=8192)
+    ap.add_argument("--ny", type=int, default=8192)
+    ap.add_argument("--workload", default="cavity", choices=["cavity", "empty", "tiled"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the nx x ny grid is split over the ranks; weak: every rank gets ny rows")
+    ap.add_argument("--accel", type=float, default=0.005)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 1024x1024 side measurement")
+    args = ap.parse_args()
+
+    import torch  # device plumbing + torch.distributed (RCCL) only
+    import lbm_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed launch with that many ranks" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    nx = args.nx
+    ny = args.ny * (world if args.scaling == "weak" else 1)
+    total_steps = args.warmup + args.steps
+    obstacles = make_workload(args.workload, nx, ny)
+    params = lbm_amd.make_params(nx, ny, total_steps, 10, 0.1, args.accel, 1.85, obstacles)
+
+    if world > 1:
+        idbuf = torch.zeros(lbm_amd.load_library().lbm_comm_id_size(), dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idbuf.copy_(torch.frombuffer(bytearray(lbm_amd.comm_id()), dtype=torch.uint8))
+        dist.broadcast(idbuf, src=0)
+        sim = lbm_amd.LBM(params, obstacles, rank=rank, nranks=world, device=local_rank,
+                          comm=bytes(idbuf.cpu().numpy().tobytes()))
+    else:
+        sim = lbm_amd.LBM(params, obstacles)
+    sim.upload(None)  # uniform rest state, built on the device
+    y0, y1 = sim.row_range()
+
+    def fence():
+        sim.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    sim.run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    loop_ms = sim.run_timed(args.steps)   # HIP events on the stream the step kernels run on
+    fence()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall, loop_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, loop_ms = float(t[0]), float(t[1])
+
+    # sanity on the result of the timed run: finite, positive average velocity on every rank
+    _, av = sim.download(cells=False)
+    ok = bool(np.all(np.isfinite(av)) and av[-1] > 0)
+
+    out = None
+    if rank == 0:
+        lups = nx * ny * args.steps / wall
+        launch_s = loop_ms * 1e-3 / args.steps
+        rows_local = y1 - y0
+        achieved = BYTES_PER_LU * nx * rows_local / launch_s / 1e9
+        out = {
+            "metric": "MLUPS", "value": round(lups / 1e6, 1), "unit": "MLUPS (million lattice updates/s)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall * 1e3 / args.steps, 5), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d %s, D2Q9-BGK fused timestep, uniform rest start" % (nx, ny, {
+                "cavity": "lid-driven cavity (4 border lines blocked)", "empty": "no obstacles (periodic)",
+                "tiled": "obstacles_1024x1024 tiled up"}[args.workload]),
+                "nx": nx, "ny": ny, "rows_per_gpu": rows_local, "partition": "rows x%d" % world,
+                "omega": 1.85, "accel": args.accel, "density": 0.1},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "d2q9_step", "launch_us": round(launch_s * 1e6, 2),
+                         "algorithmic_bytes_per_launch": BYTES_PER_LU * nx * rows_local},
+            "result_ok": ok,
+        }
+        # measured PMC traffic of the same command, when a profile of this workload is committed
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp) and world == 1:
+            with open(tp) as f:
+                tj = json.load(f)
+            key = "%dx%d" % (nx, ny)
+            if key in tj:
+                out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tj[key].get("source")
+    sim.close()
+
+    if world == 1 and rank == 0:
+        if not args.no_extra and (nx, ny) != (1024, 1024):
+            # the reference's own largest input, for the 1024x1024 figure the north star asks for
+            p2, ob2 = lbm_amd.read_inputs(os.path.join(ROOT, "inputs", "input_1024x1024.params"),
+                                          os.path.join(ROOT, "inputs", "obstacles_1024x1024.dat"))
+            n2 = 4000
+            p2.max_iters = n2 + 200
+            with lbm_amd.LBM(p2, ob2) as s2:
+                s2.upload(None)
+                s2.run(200)
+                s2.sync()
+                t1 = time.perf_counter()
+                ms2 = s2.run_timed(n2)
+                s2.sync()
+                w2 = time.perf_counter() - t1
+            out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat (fits the 256 MiB Infinity Cache)",
+                           "value": round(1024 * 1024 * n2 / w2 / 1e6, 1), "unit": "MLUPS", "steps": n2,
+                           "roofline_frac_if_hbm": round(BYTES_PER_LU * 1024 * 1024 / (ms2 * 1e-3 / n2) / 1e9 / HBM_PEAK_GBPS, 4)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx, ny, obstacles, args.accel)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,31 @@ def read_inputs(paramfile, obstaclefile):
     return make_params(nx, ny, max_iters, reynolds_dim, density, accel, omega, obstacles), obstacles
 
 
+# ---- row partition: the host-side geometry of csrc/lbm_hip.cpp (split_rows, build_slab, exchange_halos) ----
+
+# distributions that cross a slab edge in the pull scheme: a cell reads f2,f5,f6 from the row below and
+# f4,f7,f8 from the row above (kernels.cl:104-112), so a slab sends its top row's 2,5,6 north and its
+# bottom row's 4,7,8 south
+HALO_PLANES = {"to_north": [2, 5, 6], "to_south": [4, 7, 8]}
+
+
+def slab_rows(ny, nslabs, index):
+    """(first global row, row count) of slab `index` of `nslabs`: contiguous rows, sizes differ by <= 1."""
+    base, rem = divmod(ny, nslabs)
+    return index * base + min(index, rem), base + (1 if index < rem else 0)
+
+
+def ring_neighbours(nslabs, index):
+    """(south, north) neighbours on the periodic ring of slabs (the grid wraps in y, kernels.cl:91-93)."""
+    return (index + nslabs - 1) % nslabs, (index + 1) % nslabs
+
+
+def accel_row_local(ny, y0, rows):
+    """local index of the accelerated global row ny-2 (kernels.cl:18) inside a slab, or -1."""
+    ar = ny - 2
+    return ar - y0 if y0 <= ar < y0 + rows else -1
+
+
 def copy_bandwidth_gbps(nbytes=1 << 30, iters=20):
     """Measured float4 streaming-copy rate (read + write bytes per second) — the roofline denominator."""
     g = ctypes.c_double()

@@ -9,10 +9,16 @@
 // plus, on the row ny-2, the NEXT step's accelerate_flow applied while the row is still in
 // registers (exact: accelerate_flow is local to a cell and runs directly before the next gather).
 //
-// Data layout in HBM (one grid): 9 planes of rows*nx floats, plane k at k*plane_stride, x fastest
-// — the reference's SoA (d2q9-bgk.c:73) with a padded plane stride.  The obstacle mask is one
-// byte per cell.  Every thread owns VEC=4 consecutive cells of one row: all 9 loads and all 9
-// stores of a wave are whole 1-KiB contiguous segments (64 lanes x 16 B).
+// Data layout in HBM (one grid): ROW-INTERLEAVED SoA.  Row y of the grid is one contiguous block
+// of 9 plane-rows, f_k(x, y) at  y*row_stride + k*plane_stride + x  with plane_stride = the padded
+// row length and row_stride = 9*plane_stride.  Each speed is still a unit-stride fp32 stream along
+// x (coalesced float4 per lane), but the 9 streams a row update touches form 3 contiguous
+// segments (rows y-1, y, y+1) instead of 9 far-apart planes — measured +12 % on 8192x8192 over
+// the reference's plane-major SoA (d2q9-bgk.c:73), whose nine 256-MiB-apart streams collide in
+// the HBM channel interleave.  The C ABI still speaks the reference's float[9][ny][nx]; upload
+// and download convert with 2-D copies.  The obstacle mask is one byte per cell.  Every thread
+// owns VEC=4 consecutive cells of one row: all 9 loads and all 9 stores of a wave are whole
+// 1-KiB contiguous segments (64 lanes x 16 B).
 //
 // Not a translation of kernels.cl: different work decomposition (float4 rows, grid-stride,
 // wave64 shuffles), different arithmetic grouping (pairwise momentum differences, shared
@@ -35,7 +41,8 @@ struct StepArgs {
   float *send_south;          // [3][nx]: planes 4,7,8 of the new row 0, or nullptr
   float *send_north;          // [3][nx]: planes 2,5,6 of the new row rows-1, or nullptr
   float *partials;            // [gridDim.x] per-workgroup sums of |j|/rho
-  unsigned long long plane_stride;  // floats between planes
+  unsigned long long plane_stride;  // floats between the 9 plane-rows of one grid row (>= nx)
+  unsigned long long row_stride;    // floats between consecutive grid rows (>= 9*plane_stride)
   int nx, rows;               // row length, rows held in this grid
   int y_begin, y_count, y_step;  // rows y_begin + r*y_step, r < y_count, are processed
   int accel_row;              // local row that gets the next step's accelerate_flow, or -1
@@ -129,67 +136,144 @@ __device__ __forceinline__ void block_store_partial(float v, float *partials) {
   }
 }
 
-// ---- variant 1: direct loads ---------------------------------------------------------------
-// Each thread loads its 9 aligned float4 (VEC=4) and, for the six x-shifted planes, the one
-// neighbouring element from the adjacent thread's segment (an L1 hit: the line is being loaded by
-// that thread anyway).  HBM traffic is exactly 9 floats in + 9 floats out + 1 mask byte per cell.
-template <int VEC, bool NT>
-__global__ __launch_bounds__(kBlock) void d2q9_step_direct(const StepArgs a) {
+// ---- the step kernel ---------------------------------------------------------------------------
+// How a thread obtains the x-1 / x+1 neighbours of its four cells (planes 1,5,8 stream from the
+// west, 3,6,7 from the east).  HBM traffic is identical in all modes — 9 floats in + 9 floats out
+// + 1 mask byte per cell; the modes differ in L1/LDS/VALU work only.
+enum LoadMode {
+  LM_SCALAR = 0,     // aligned float4 + one scalar load of the neighbour element (an L1 hit)
+  LM_UNALIGNED = 1,  // one 4-byte-aligned 16-byte load at x-1 / x+1
+  LM_DPP = 2,        // aligned float4 + wave64 DPP shift of the edge component; lanes 0/63 load the halo
+  LM_LDS = 3,        // aligned float4 staged through a per-wave LDS row with a one-cell halo, read back shifted
+};
+
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+
+__device__ __forceinline__ float dpp_from_lane_below(float v, float lane0_value) {
+  // lane i receives lane i-1; lane 0 keeps lane0_value
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_value), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_lane_above(float v, float lane63_value) {
+  // lane i receives lane i+1; lane 63 keeps lane63_value
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane63_value), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+constexpr int kLdsRow = 256 + 8;  // per-wave staged row: [3 pad][W halo][256 cells][E halo][3 pad]
+
+template <int VEC, bool NT, int LM>
+__global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
   const unsigned tpr = (unsigned)a.nx / VEC;  // threads per row
   const unsigned total = tpr * (unsigned)a.y_count;
   const size_t ps = a.plane_stride;
+  const size_t rs = a.row_stride;
   float tot_u = 0.0f;
+  __shared__ float stage[(LM == LM_LDS) ? (kBlock / 64) * 6 * kLdsRow : 1];
 
   for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
     const unsigned r = t / tpr;
     const int x0 = (int)(t - r * tpr) * VEC;
     const int y = a.y_begin + (int)r * a.y_step;
-    const size_t row = (size_t)y * a.nx;
+    const size_t row = (size_t)y * rs;
     // neighbour columns with periodic wrap (kernels.cl:99-102)
     const int xw = (x0 == 0) ? a.nx - 1 : x0 - 1;
     const int xe = (x0 + VEC >= a.nx) ? 0 : x0 + VEC;
     // source rows: same row for planes 0,1,3; south row for 2,5,6; north row for 4,7,8
     const float *rc = a.src + row;
     const bool at_south = (y == 0), at_north = (y == a.rows - 1);
-    const float *r2 = at_south ? a.south_src[0] : a.src + 2 * ps + row - a.nx;
-    const float *r5 = at_south ? a.south_src[1] : a.src + 5 * ps + row - a.nx;
-    const float *r6 = at_south ? a.south_src[2] : a.src + 6 * ps + row - a.nx;
-    const float *r4 = at_north ? a.north_src[0] : a.src + 4 * ps + row + a.nx;
-    const float *r7 = at_north ? a.north_src[1] : a.src + 7 * ps + row + a.nx;
-    const float *r8 = at_north ? a.north_src[2] : a.src + 8 * ps + row + a.nx;
+    const float *r2 = at_south ? a.south_src[0] : a.src + 2 * ps + row - rs;
+    const float *r5 = at_south ? a.south_src[1] : a.src + 5 * ps + row - rs;
+    const float *r6 = at_south ? a.south_src[2] : a.src + 6 * ps + row - rs;
+    const float *r4 = at_north ? a.north_src[0] : a.src + 4 * ps + row + rs;
+    const float *r7 = at_north ? a.north_src[1] : a.src + 7 * ps + row + rs;
+    const float *r8 = at_north ? a.north_src[2] : a.src + 8 * ps + row + rs;
     const float *r1 = rc + 1 * ps, *r3 = rc + 3 * ps;
 
     float g[9][VEC];
     bool obst[VEC];
     if constexpr (VEC == 4) {
-      // issue all loads before any use
+      // all loads are issued before any use
       const float4 c0 = *reinterpret_cast<const float4 *>(rc + x0);
-      const float4 c1 = *reinterpret_cast<const float4 *>(r1 + x0);
       const float4 c2 = *reinterpret_cast<const float4 *>(r2 + x0);
-      const float4 c3 = *reinterpret_cast<const float4 *>(r3 + x0);
       const float4 c4 = *reinterpret_cast<const float4 *>(r4 + x0);
-      const float4 c5 = *reinterpret_cast<const float4 *>(r5 + x0);
-      const float4 c6 = *reinterpret_cast<const float4 *>(r6 + x0);
-      const float4 c7 = *reinterpret_cast<const float4 *>(r7 + x0);
-      const float4 c8 = *reinterpret_cast<const float4 *>(r8 + x0);
-      const float w1 = r1[xw], w5 = r5[xw], w8 = r8[xw];
-      const float e3 = r3[xe], e6 = r6[xe], e7 = r7[xe];
-      const uint32_t m = *reinterpret_cast<const uint32_t *>(a.mask + row + x0);
+      const uint32_t m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)y * a.nx + x0);
       g[0][0] = c0.x; g[0][1] = c0.y; g[0][2] = c0.z; g[0][3] = c0.w;
       g[2][0] = c2.x; g[2][1] = c2.y; g[2][2] = c2.z; g[2][3] = c2.w;
       g[4][0] = c4.x; g[4][1] = c4.y; g[4][2] = c4.z; g[4][3] = c4.w;
-      g[1][0] = w1;   g[1][1] = c1.x; g[1][2] = c1.y; g[1][3] = c1.z;   // from x-1
-      g[5][0] = w5;   g[5][1] = c5.x; g[5][2] = c5.y; g[5][3] = c5.z;
-      g[8][0] = w8;   g[8][1] = c8.x; g[8][2] = c8.y; g[8][3] = c8.z;
-      g[3][0] = c3.y; g[3][1] = c3.z; g[3][2] = c3.w; g[3][3] = e3;     // from x+1
-      g[6][0] = c6.y; g[6][1] = c6.z; g[6][2] = c6.w; g[6][3] = e6;
-      g[7][0] = c7.y; g[7][1] = c7.z; g[7][2] = c7.w; g[7][3] = e7;
       obst[0] = (m & 0xffu) != 0; obst[1] = (m & 0xff00u) != 0;
       obst[2] = (m & 0xff0000u) != 0; obst[3] = (m & 0xff000000u) != 0;
+      if constexpr (LM == LM_UNALIGNED) {
+        // x0 == 0 / x0+4 == nx wrap around the row: those two threads per row take the scalar path
+        const bool wrap_w = (x0 == 0), wrap_e = (x0 + 4 >= a.nx);
+        const int ow = wrap_w ? 0 : -1, oe = wrap_e ? 0 : 1;
+        f4u w1 = *reinterpret_cast<const f4u *>(r1 + x0 + ow), w5 = *reinterpret_cast<const f4u *>(r5 + x0 + ow),
+            w8 = *reinterpret_cast<const f4u *>(r8 + x0 + ow);
+        f4u e3 = *reinterpret_cast<const f4u *>(r3 + x0 + oe), e6 = *reinterpret_cast<const f4u *>(r6 + x0 + oe),
+            e7 = *reinterpret_cast<const f4u *>(r7 + x0 + oe);
+        if (wrap_w) {
+          w1 = f4u{r1[xw], w1.x, w1.y, w1.z}; w5 = f4u{r5[xw], w5.x, w5.y, w5.z}; w8 = f4u{r8[xw], w8.x, w8.y, w8.z};
+        }
+        if (wrap_e) {
+          e3 = f4u{e3.y, e3.z, e3.w, r3[xe]}; e6 = f4u{e6.y, e6.z, e6.w, r6[xe]}; e7 = f4u{e7.y, e7.z, e7.w, r7[xe]};
+        }
+        g[1][0] = w1.x; g[1][1] = w1.y; g[1][2] = w1.z; g[1][3] = w1.w;
+        g[5][0] = w5.x; g[5][1] = w5.y; g[5][2] = w5.z; g[5][3] = w5.w;
+        g[8][0] = w8.x; g[8][1] = w8.y; g[8][2] = w8.z; g[8][3] = w8.w;
+        g[3][0] = e3.x; g[3][1] = e3.y; g[3][2] = e3.z; g[3][3] = e3.w;
+        g[6][0] = e6.x; g[6][1] = e6.y; g[6][2] = e6.z; g[6][3] = e6.w;
+        g[7][0] = e7.x; g[7][1] = e7.y; g[7][2] = e7.z; g[7][3] = e7.w;
+      } else {
+        const float4 c1 = *reinterpret_cast<const float4 *>(r1 + x0);
+        const float4 c3 = *reinterpret_cast<const float4 *>(r3 + x0);
+        const float4 c5 = *reinterpret_cast<const float4 *>(r5 + x0);
+        const float4 c6 = *reinterpret_cast<const float4 *>(r6 + x0);
+        const float4 c7 = *reinterpret_cast<const float4 *>(r7 + x0);
+        const float4 c8 = *reinterpret_cast<const float4 *>(r8 + x0);
+        float w1, w5, w8, e3, e6, e7;
+        if constexpr (LM == LM_SCALAR) {
+          w1 = r1[xw]; w5 = r5[xw]; w8 = r8[xw];
+          e3 = r3[xe]; e6 = r6[xe]; e7 = r7[xe];
+        } else if constexpr (LM == LM_DPP) {
+          // requires whole waves inside one row (tpr % 64 == 0): lane i-1 / i+1 hold x0-4 / x0+4
+          const int lane = threadIdx.x & 63;
+          float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+          if (lane == 0 || lane == 63) {
+            // one masked load per plane pair: lane 0 fetches the west halo, lane 63 the east halo
+            const bool lo = (lane == 0);
+            h0 = lo ? r1[xw] : r3[xe];
+            h1 = lo ? r5[xw] : r6[xe];
+            h2 = lo ? r8[xw] : r7[xe];
+          }
+          w1 = dpp_from_lane_below(c1.w, h0); w5 = dpp_from_lane_below(c5.w, h1); w8 = dpp_from_lane_below(c8.w, h2);
+          e3 = dpp_from_lane_above(c3.x, h0); e6 = dpp_from_lane_above(c6.x, h1); e7 = dpp_from_lane_above(c7.x, h2);
+        } else {  // LM_LDS
+          const int lane = threadIdx.x & 63;
+          float *st = stage + (threadIdx.x >> 6) * 6 * kLdsRow;
+          float *s1 = st, *s5 = st + kLdsRow, *s8 = st + 2 * kLdsRow, *s3 = st + 3 * kLdsRow, *s6 = st + 4 * kLdsRow,
+                *s7 = st + 5 * kLdsRow;
+          const int o = 4 + 4 * lane;
+          *reinterpret_cast<float4 *>(s1 + o) = c1; *reinterpret_cast<float4 *>(s5 + o) = c5;
+          *reinterpret_cast<float4 *>(s8 + o) = c8; *reinterpret_cast<float4 *>(s3 + o) = c3;
+          *reinterpret_cast<float4 *>(s6 + o) = c6; *reinterpret_cast<float4 *>(s7 + o) = c7;
+          if (lane == 0) { s1[3] = r1[xw]; s5[3] = r5[xw]; s8[3] = r8[xw]; }
+          if (lane == 63) { s3[4 + 256] = r3[xe]; s6[4 + 256] = r6[xe]; s7[4 + 256] = r7[xe]; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          w1 = s1[o - 1]; w5 = s5[o - 1]; w8 = s8[o - 1];
+          e3 = s3[o + 4]; e6 = s6[o + 4]; e7 = s7[o + 4];
+          __builtin_amdgcn_wave_barrier();
+        }
+        g[1][0] = w1;   g[1][1] = c1.x; g[1][2] = c1.y; g[1][3] = c1.z;   // from x-1
+        g[5][0] = w5;   g[5][1] = c5.x; g[5][2] = c5.y; g[5][3] = c5.z;
+        g[8][0] = w8;   g[8][1] = c8.x; g[8][2] = c8.y; g[8][3] = c8.z;
+        g[3][0] = c3.y; g[3][1] = c3.z; g[3][2] = c3.w; g[3][3] = e3;     // from x+1
+        g[6][0] = c6.y; g[6][1] = c6.z; g[6][2] = c6.w; g[6][3] = e6;
+        g[7][0] = c7.y; g[7][1] = c7.z; g[7][2] = c7.w; g[7][3] = e7;
+      }
     } else {
       g[0][0] = rc[x0]; g[1][0] = r1[xw]; g[2][0] = r2[x0]; g[3][0] = r3[xe]; g[4][0] = r4[x0];
       g[5][0] = r5[xw]; g[6][0] = r6[xe]; g[7][0] = r7[xe]; g[8][0] = r8[xw];
-      obst[0] = a.mask[row + x0] != 0;
+      obst[0] = a.mask[(size_t)y * a.nx + x0] != 0;
     }
 
     float o[9][VEC];
@@ -253,13 +337,13 @@ __global__ __launch_bounds__(kBlock) void reduce_partials(const float *partials,
 }
 
 // ---- stand-alone accelerate_flow (kernels.cl:9-53): prologue of a run ---------------------------
-__global__ void accelerate_row(float *cells, unsigned long long plane_stride, const uint8_t *mask, int nx, int row,
-                               float aw1, float aw2) {
+__global__ void accelerate_row(float *cells, unsigned long long plane_stride, unsigned long long row_stride,
+                               const uint8_t *mask, int nx, int row, float aw1, float aw2) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= nx) return;
-  const size_t c = (size_t)row * nx + x;
+  const size_t c = (size_t)row * row_stride + x;
   float f3 = cells[3 * plane_stride + c], f6 = cells[6 * plane_stride + c], f7 = cells[7 * plane_stride + c];
-  if (mask[c] == 0 && (f3 - aw1) > 0.0f && (f6 - aw2) > 0.0f && (f7 - aw2) > 0.0f) {
+  if (mask[(size_t)row * nx + x] == 0 && (f3 - aw1) > 0.0f && (f6 - aw2) > 0.0f && (f7 - aw2) > 0.0f) {
     cells[1 * plane_stride + c] += aw1;
     cells[5 * plane_stride + c] += aw2;
     cells[8 * plane_stride + c] += aw2;
@@ -270,11 +354,11 @@ __global__ void accelerate_row(float *cells, unsigned long long plane_stride, co
 }
 
 // packs the boundary rows of a grid into the halo send buffers (start of a run, slab mode)
-__global__ void pack_halo_rows(const float *cells, unsigned long long plane_stride, int nx, int rows,
-                               float *send_south, float *send_north) {
+__global__ void pack_halo_rows(const float *cells, unsigned long long plane_stride, unsigned long long row_stride, int nx,
+                               int rows, float *send_south, float *send_north) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= nx) return;
-  const size_t top = (size_t)(rows - 1) * nx + x;
+  const size_t top = (size_t)(rows - 1) * row_stride + x;
   send_south[0 * nx + x] = cells[4 * plane_stride + x];
   send_south[1 * nx + x] = cells[7 * plane_stride + x];
   send_south[2 * nx + x] = cells[8 * plane_stride + x];
@@ -284,8 +368,11 @@ __global__ void pack_halo_rows(const float *cells, unsigned long long plane_stri
 }
 
 // ---- initial state on the device (values of d2q9-bgk.c:529-550) ---------------------------------
-__global__ void init_cells(float *cells, unsigned long long plane_stride, size_t n, float w0, float w1, float w2) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+__global__ void init_cells(float *cells, unsigned long long plane_stride, unsigned long long row_stride, int nx,
+                           size_t n, float w0, float w1, float w2) {
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
+    const size_t y = c / nx;
+    const size_t i = y * row_stride + (c - y * nx);
     cells[i] = w0;
 #pragma unroll
     for (int k = 1; k <= 4; k++) cells[k * plane_stride + i] = w1;
@@ -296,8 +383,9 @@ __global__ void init_cells(float *cells, unsigned long long plane_stride, size_t
 
 // ---- output stage: columns of final_state.dat + velocity sum (d2q9-bgk.c:787-832, 396-442) ------
 __global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsigned long long plane_stride,
-                                                       const uint8_t *mask, size_t n, float density, float *u_x,
-                                                       float *u_y, float *u, float *pressure, float *partials) {
+                                                       unsigned long long row_stride, int nx, const uint8_t *mask,
+                                                       size_t n, float density, float *u_x, float *u_y, float *u,
+                                                       float *pressure, float *partials) {
   const float c_sq = 1.0f / 3.0f;
   float tot_u = 0.0f;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
@@ -305,9 +393,11 @@ __global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsig
     if (mask[i] == 0) {
       float f[9];
       float local_density = 0.0f;
+      const size_t y = i / nx;
+      const size_t cell = y * row_stride + (i - y * nx);
 #pragma unroll
       for (int k = 0; k < 9; k++) {
-        f[k] = cells[k * plane_stride + i];
+        f[k] = cells[k * plane_stride + cell];
         local_density += f[k];
       }
       ux = (f[1] + f[5] + f[8] - f[3] - f[6] - f[7]) / local_density;

@@ -96,7 +96,7 @@ int load_rccl() {
                   g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?");                      \
   } while (0)
 
-constexpr int kRing = 256;  // steps of per-workgroup partial sums buffered between reductions
+constexpr int kRingMax = 256;  // most steps of per-workgroup partial sums buffered between reductions
 enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2 };
 
 struct Slab {
@@ -104,13 +104,14 @@ struct Slab {
   int index = 0;          // position in the global ring of slabs
   int y0 = 0, rows = 0;   // global first row, rows held
   int accel_row = -1;     // local index of global row ny-2, or -1
-  size_t plane_stride = 0;
+  size_t plane_stride = 0;  // floats between the 9 plane-rows of a grid row (padded row length)
+  size_t row_stride = 0;    // floats between grid rows = 9*plane_stride (+ pad)
   float *cells[2] = {nullptr, nullptr};
   uint8_t *mask = nullptr;
   // halo buffers, 3*nx floats each: [parity][0 = south side, 1 = north side]
   float *halo_send[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   float *halo_recv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  float *partials = nullptr;  // [kRing][nb_total]
+  float *partials = nullptr;  // [ring][nb_total]
   int nb_main = 0, nb_edge = 0, nb_total = 0;
   double *av_sum = nullptr;   // [capacity] per-step sum of |j|/rho over this slab's fluid cells
   hipStream_t s_main = nullptr, s_edge = nullptr;
@@ -135,6 +136,7 @@ struct lbm_ctx {
   int cur = 0;              // index of the grid holding the current state
   int steps_done = 0;
   int ring_fill = 0;        // buffered steps not yet reduced
+  int ring = kRingMax;      // slots in the partial-sum ring (smaller for grids with many workgroups)
   int transport = TRANSPORT_AUTO;
   int transport_eff = TRANSPORT_COPY;
   // options
@@ -167,27 +169,49 @@ int dev_alloc(T **p, size_t count) {
 int step_blocks(const lbm_ctx *c, int work_rows) {
   const int vec = c->vec4 ? 4 : 1;
   const long threads = (long)(c->p.nx / vec) * work_rows;
+  // default: one 256-thread tile per workgroup, no grid-stride.  Measured on 8192x8192: 65536 one-tile
+  // workgroups 0.795 ms/step vs 0.85 ms with 2048 persistent ones (the dispatcher walks the grid in
+  // address order and keeps every CU's queue full; profiles/r01_tune.txt)
   int nb = div_up(threads, kBlock);
-  int cap = c->grid_blocks > 0 ? c->grid_blocks : 256 * 16;
-  nb = std::max(1, std::min(nb, cap));
-  return nb;
+  if (c->grid_blocks > 0) nb = std::min(nb, c->grid_blocks);
+  return std::max(1, nb);
 }
 
 bool nt_effective(const lbm_ctx *c) {
   if (c->nt_stores >= 0) return c->nt_stores != 0;
   // both grids of a slab fit the 256 MiB Infinity Cache -> keep the written lines cacheable
-  const size_t grid_bytes = (size_t)9 * c->slabs[0].plane_stride * sizeof(float);
+  const size_t grid_bytes = c->slabs[0].row_stride * c->slabs[0].rows * sizeof(float);
   return 2 * grid_bytes > ((size_t)192 << 20);
+}
+
+// which LoadMode a context uses: option "variant" 1..4 = LM_SCALAR, LM_UNALIGNED, LM_DPP, LM_LDS;
+// 0 = auto.  The wave-level modes need whole waves inside one row (nx % 256 == 0).
+int effective_mode(const lbm_ctx *c) {
+  if (!c->vec4) return LM_SCALAR;
+  const bool wave_rows = (c->p.nx % 256 == 0);
+  int m = c->variant > 0 ? c->variant - 1 : (wave_rows ? LM_DPP : LM_SCALAR);
+  if ((m == LM_DPP || m == LM_LDS) && !wave_rows) m = LM_SCALAR;
+  return m;
+}
+
+template <int LM>
+void launch_step_lm(bool nt, const StepArgs &a, int nblocks, hipStream_t st) {
+  if (nt) hipLaunchKernelGGL((d2q9_step<4, true, LM>), dim3(nblocks), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((d2q9_step<4, false, LM>), dim3(nblocks), dim3(kBlock), 0, st, a);
 }
 
 void launch_step(const lbm_ctx *c, const StepArgs &a, int nblocks, hipStream_t st) {
   const bool nt = nt_effective(c);
-  if (c->vec4) {
-    if (nt) hipLaunchKernelGGL((d2q9_step_direct<4, true>), dim3(nblocks), dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((d2q9_step_direct<4, false>), dim3(nblocks), dim3(kBlock), 0, st, a);
-  } else {
-    if (nt) hipLaunchKernelGGL((d2q9_step_direct<1, true>), dim3(nblocks), dim3(kBlock), 0, st, a);
-    else hipLaunchKernelGGL((d2q9_step_direct<1, false>), dim3(nblocks), dim3(kBlock), 0, st, a);
+  if (!c->vec4) {
+    if (nt) hipLaunchKernelGGL((d2q9_step<1, true, LM_SCALAR>), dim3(nblocks), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL((d2q9_step<1, false, LM_SCALAR>), dim3(nblocks), dim3(kBlock), 0, st, a);
+    return;
+  }
+  switch (effective_mode(c)) {
+    case LM_UNALIGNED: launch_step_lm<LM_UNALIGNED>(nt, a, nblocks, st); break;
+    case LM_DPP: launch_step_lm<LM_DPP>(nt, a, nblocks, st); break;
+    case LM_LDS: launch_step_lm<LM_LDS>(nt, a, nblocks, st); break;
+    default: launch_step_lm<LM_SCALAR>(nt, a, nblocks, st); break;
   }
 }
 
@@ -197,6 +221,7 @@ StepArgs base_args(const lbm_ctx *c, const Slab &s, int src, bool apply_accel) {
   a.dst = s.cells[src ^ 1];
   a.mask = s.mask;
   a.plane_stride = s.plane_stride;
+  a.row_stride = s.row_stride;
   a.nx = c->p.nx;
   a.rows = s.rows;
   a.accel_row = apply_accel ? s.accel_row : -1;
@@ -255,7 +280,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     if (multi) HIP_TRY(hipStreamSynchronize(s.s_edge));
     if (s.accel_row >= 0) {
       hipLaunchKernelGGL(accelerate_row, dim3(div_up(nx, 128)), dim3(128), 0, s.s_main, s.cells[c->cur], s.plane_stride,
-                         s.mask, nx, s.accel_row, aw1, aw2);
+                         s.row_stride, s.mask, nx, s.accel_row, aw1, aw2);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -264,8 +289,8 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     // they were the result of step "-1" (parity 1)
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
-      hipLaunchKernelGGL(pack_halo_rows, dim3(div_up(nx, 128)), dim3(128), 0, s.s_main, s.cells[c->cur], s.plane_stride, nx,
-                         s.rows, s.halo_send[1][0], s.halo_send[1][1]);
+      hipLaunchKernelGGL(pack_halo_rows, dim3(div_up(nx, 128)), dim3(128), 0, s.s_main, s.cells[c->cur], s.plane_stride,
+                         s.row_stride, nx, s.rows, s.halo_send[1][0], s.halo_send[1][1]);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(s.ev_main[1], s.s_main));
       HIP_TRY(hipEventRecord(s.ev_edgek[1], s.s_main));
@@ -294,7 +319,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       StepArgs a = base_args(c, s, src, !last);
       for (int k = 0; k < 3; k++) {
         static const int sp[3] = {2, 5, 6}, np[3] = {4, 7, 8};
-        a.south_src[k] = s.cells[src] + sp[k] * s.plane_stride + (size_t)(s.rows - 1) * nx;  // y wrap (kernels.cl:91-93)
+        a.south_src[k] = s.cells[src] + sp[k] * s.plane_stride + (size_t)(s.rows - 1) * s.row_stride;  // y wrap (kernels.cl:91-93)
         a.north_src[k] = s.cells[src] + np[k] * s.plane_stride;
       }
       a.y_begin = 0; a.y_count = s.rows; a.y_step = 1;
@@ -338,7 +363,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     }
     c->cur ^= 1;
     c->ring_fill++;
-    if (c->ring_fill == kRing || last) {
+    if (c->ring_fill == c->ring || last) {
       // flush_ring needs the parity of the last edge kernel
       const int lastq = q;
       const int fill = c->ring_fill;
@@ -434,11 +459,12 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   HIP_TRY(hipEventCreate(&s.ev_t1));
   HIP_TRY(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
   const size_t n = (size_t)nx * s.rows;
-  // plane stride: whole 256-B lines plus one odd line so that the nine planes do not all start at
-  // the same offset of a power-of-two sized plane (HBM channel interleave)
-  s.plane_stride = ((n + 63) / 64) * 64 + 64 * 5;
+  // row-interleaved SoA (see d2q9_kernels.h): plane-rows padded to whole 256-B lines
+  s.plane_stride = ((size_t)(nx + 63) / 64) * 64;
+  const char *pad_env = getenv("LBM_ROW_PAD");  // extra floats between grid rows (tuning only)
+  s.row_stride = 9 * s.plane_stride + (pad_env ? (size_t)atol(pad_env) / 4 * 4 : 0);
   for (int i = 0; i < 2; i++) {
-    if (dev_alloc(&s.cells[i], 9 * s.plane_stride)) return LBM_ERR_HIP;
+    if (dev_alloc(&s.cells[i], s.row_stride * s.rows + 64)) return LBM_ERR_HIP;
   }
   if (dev_alloc(&s.mask, n + 64)) return LBM_ERR_HIP;
   {
@@ -462,10 +488,24 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
     s.nb_edge = 0;
   }
   s.nb_total = s.nb_main + s.nb_edge;
-  if (dev_alloc(&s.partials, (size_t)kRing * s.nb_total)) return LBM_ERR_HIP;
   if (dev_alloc(&s.av_sum, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
   s.fin_blocks = std::max(1, std::min(div_up((long)n, kBlock), 2048));
   if (dev_alloc(&s.fin_partials, (size_t)s.fin_blocks)) return LBM_ERR_HIP;
+  return LBM_OK;
+}
+
+// (Re)allocate the ring of per-workgroup partial sums: [ring][nb_total] floats per slab, at most 16 MiB.
+int alloc_partials(lbm_ctx *c) {
+  int max_nb = 1;
+  for (Slab &s : c->slabs) max_nb = std::max(max_nb, s.nb_total);
+  c->ring = (int)std::max<long>(8, std::min<long>(kRingMax, (4L << 20) / max_nb));
+  for (Slab &s : c->slabs) {
+    if (set_dev(s)) return LBM_ERR_HIP;
+    if (s.partials) HIP_TRY(hipFree(s.partials));
+    s.partials = nullptr;
+    if (dev_alloc(&s.partials, (size_t)c->ring * s.nb_total)) return LBM_ERR_HIP;
+  }
+  c->ring_fill = 0;
   return LBM_OK;
 }
 
@@ -489,11 +529,8 @@ int rebuild_geometry(lbm_ctx *c) {
       s.nb_edge = 0;
     }
     s.nb_total = s.nb_main + s.nb_edge;
-    if (s.partials) HIP_TRY(hipFree(s.partials));
-    s.partials = nullptr;
-    if (dev_alloc(&s.partials, (size_t)kRing * s.nb_total)) return LBM_ERR_HIP;
   }
-  return LBM_OK;
+  return alloc_partials(c);
 }
 
 }  // namespace
@@ -546,6 +583,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     split_rows(params->ny, nslabs_global, s.index, &s.y0, &s.rows);
     rc = build_slab(c, s, obstacles);
   }
+  if (rc == LBM_OK) rc = alloc_partials(c);
   // transport for halo exchange
   if (rc == LBM_OK && nslabs_global > 1) {
     bool dup = false;
@@ -638,14 +676,16 @@ int lbm_upload(lbm_ctx *c, const float *cells) {
     if (set_dev(s)) return LBM_ERR_HIP;
     const size_t n = (size_t)nx * s.rows;
     if (cells) {
+      // reference SoA plane k (d2q9-bgk.c:73) -> plane-row k of every grid row
       for (int k = 0; k < 9; k++)
-        HIP_TRY(hipMemcpyAsync(s.cells[0] + k * s.plane_stride, cells + k * n_global + (size_t)s.y0 * nx, n * sizeof(float),
-                               hipMemcpyHostToDevice, s.s_main));
+        HIP_TRY(hipMemcpy2DAsync(s.cells[0] + k * s.plane_stride, s.row_stride * sizeof(float),
+                                 cells + k * n_global + (size_t)s.y0 * nx, (size_t)nx * sizeof(float),
+                                 (size_t)nx * sizeof(float), s.rows, hipMemcpyHostToDevice, s.s_main));
     } else {
       // d2q9-bgk.c:529-531
       const float w0 = c->p.density * 4.0f / 9.0f, w1 = c->p.density / 9.0f, w2 = c->p.density / 36.0f;
       hipLaunchKernelGGL(init_cells, dim3(std::min(div_up((long)n, 256), 4096)), dim3(256), 0, s.s_main, s.cells[0],
-                         s.plane_stride, n, w0, w1, w2);
+                         s.plane_stride, s.row_stride, nx, n, w0, w1, w2);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(s.s_main));
@@ -693,10 +733,10 @@ int lbm_download(lbm_ctx *c, float *cells_out, float *av_vels_out) {
   if (cells_out) {
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
-      const size_t n = (size_t)nx * s.rows;
       for (int k = 0; k < 9; k++)
-        HIP_TRY(hipMemcpyAsync(cells_out + k * n_global + (size_t)s.y0 * nx, s.cells[c->cur] + k * s.plane_stride,
-                               n * sizeof(float), hipMemcpyDeviceToHost, s.s_main));
+        HIP_TRY(hipMemcpy2DAsync(cells_out + k * n_global + (size_t)s.y0 * nx, (size_t)nx * sizeof(float),
+                                 s.cells[c->cur] + k * s.plane_stride, s.row_stride * sizeof(float),
+                                 (size_t)nx * sizeof(float), s.rows, hipMemcpyDeviceToHost, s.s_main));
       HIP_TRY(hipStreamSynchronize(s.s_main));
     }
   }
@@ -742,8 +782,8 @@ int lbm_final_state(lbm_ctx *c, float *u_x, float *u_y, float *u, float *pressur
     float *d[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; i++)
       if (outs[i] && dev_alloc(&d[i], n)) return LBM_ERR_HIP;
-    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.cells[c->cur], s.plane_stride, s.mask,
-                       n, c->p.density, d[0], d[1], d[2], d[3], s.fin_partials);
+    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.cells[c->cur], s.plane_stride,
+                       s.row_stride, nx, s.mask, n, c->p.density, d[0], d[1], d[2], d[3], s.fin_partials);
     hipError_t e = hipGetLastError();
     for (int i = 0; i < 4 && e == hipSuccess; i++)
       if (outs[i]) e = hipMemcpyAsync(outs[i] + (size_t)s.y0 * nx, d[i], n * sizeof(float), hipMemcpyDeviceToHost, s.s_main);
@@ -762,9 +802,9 @@ int lbm_reynolds(lbm_ctx *c, float *reynolds_out) {
   for (Slab &s : c->slabs) {
     if (set_dev(s)) return LBM_ERR_HIP;
     const size_t n = (size_t)c->p.nx * s.rows;
-    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.cells[c->cur], s.plane_stride, s.mask,
-                       n, c->p.density, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr,
-                       s.fin_partials);
+    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.cells[c->cur], s.plane_stride,
+                       s.row_stride, c->p.nx, s.mask, n, c->p.density, (float *)nullptr, (float *)nullptr, (float *)nullptr,
+                       (float *)nullptr, s.fin_partials);
     HIP_TRY(hipGetLastError());
     std::vector<float> part(s.fin_blocks);
     HIP_TRY(hipMemcpyAsync(part.data(), s.fin_partials, sizeof(float) * s.fin_blocks, hipMemcpyDeviceToHost, s.s_main));
@@ -794,7 +834,7 @@ int lbm_reynolds(lbm_ctx *c, float *reynolds_out) {
 int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   if (!c || !key) return fail(LBM_ERR_ARG, "NULL argument");
   if (!strcmp(key, "variant")) {
-    if (value < 0 || value > 3) return fail(LBM_ERR_ARG, "variant must be 0..3");
+    if (value < 0 || value > 4) return fail(LBM_ERR_ARG, "variant must be 0..4");
     c->variant = (int)value;
     return LBM_OK;
   }
@@ -812,7 +852,7 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
 
 int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   if (!c || !key || !value) return fail(LBM_ERR_ARG, "NULL argument");
-  if (!strcmp(key, "variant")) *value = c->variant;
+  if (!strcmp(key, "variant")) *value = effective_mode(c) + 1;
   else if (!strcmp(key, "grid_blocks")) *value = c->slabs.empty() ? 0 : c->slabs[0].nb_main;
   else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
   else if (!strcmp(key, "use_graph")) *value = c->use_graph;

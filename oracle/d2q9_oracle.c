@@ -115,10 +115,15 @@ void oracle_init_cells(const oracle_params *p, REAL *cells)
 /* kernels.cl:9-53 */
 void oracle_accelerate_flow(const oracle_params *p, REAL *cells, const int *obstacles)
 {
+  oracle_accelerate_row(p, cells, obstacles, p->ny - 2); /* kernels.cl:18 */
+}
+
+void oracle_accelerate_row(const oracle_params *p, REAL *cells, const int *obstacles, int row)
+{
   const int nx = p->nx, ny = p->ny;
   const REAL w1 = p->density * p->accel / (REAL)9;
   const REAL w2 = p->density * p->accel / (REAL)36;
-  const int ii = ny - 2; /* kernels.cl:18 */
+  const int ii = row;
   for (int jj = 0; jj < nx; jj++) {
     REAL r3 = cells[IDX(jj, ii, 3, nx, ny)];
     REAL r6 = cells[IDX(jj, ii, 6, nx, ny)];
@@ -222,6 +227,13 @@ REAL oracle_timestep(const oracle_params *p, const REAL *src, REAL *dst, const i
   for (int ii = 0; ii < ny; ii++) tot_u += row_sums[ii];
   free(row_sums);
   return (REAL)(tot_u * (double)p->free_cells_inv);
+}
+
+double oracle_timestep_rows(const oracle_params *p, const REAL *src, REAL *dst, const int *obstacles, int y0, int y1)
+{
+  double tot_u = 0.0;
+  for (int ii = y0; ii < y1; ii++) tot_u += timestep_row(p, src, dst, obstacles, ii);
+  return tot_u;
 }
 
 /* d2q9-bgk.c:221-238 */

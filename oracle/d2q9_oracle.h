@@ -49,6 +49,10 @@ void oracle_init_cells(const oracle_params *p, REAL *cells);
 void oracle_accelerate_flow(const oracle_params *p, REAL *cells, const int *obstacles);
 /* kernels.cl:56-231 — pull-stream + rebound + collide src->dst; returns av_vels[t] */
 REAL oracle_timestep(const oracle_params *p, const REAL *src, REAL *dst, const int *obstacles);
+/* The same two kernels restricted to chosen rows (used by the row-partition tests): accelerate a given
+ * row instead of ny-2; compute only rows [y0, y1) of dst and return the RAW sum of |j|/rho over them */
+void oracle_accelerate_row(const oracle_params *p, REAL *cells, const int *obstacles, int row);
+double oracle_timestep_rows(const oracle_params *p, const REAL *src, REAL *dst, const int *obstacles, int y0, int y1);
 /* d2q9-bgk.c:221-238 loop: nsteps of accelerate+timestep with ping-pong; the final state is
  * always left in `cells` (copied back when nsteps is odd).  av_vels may be NULL. */
 void oracle_run(const oracle_params *p, REAL *cells, REAL *tmp_cells, const int *obstacles,

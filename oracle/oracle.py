@@ -54,6 +54,9 @@ class Oracle:
         L.oracle_accelerate_flow.argtypes = [P, rp, ip]
         L.oracle_timestep.argtypes = [P, rp, rp, ip]
         L.oracle_timestep.restype = creal
+        L.oracle_accelerate_row.argtypes = [P, rp, ip, ctypes.c_int]
+        L.oracle_timestep_rows.argtypes = [P, rp, rp, ip, ctypes.c_int, ctypes.c_int]
+        L.oracle_timestep_rows.restype = ctypes.c_double
         L.oracle_run.argtypes = [P, rp, rp, ip, ctypes.c_void_p, ctypes.c_int]
         L.oracle_av_velocity.argtypes = [P, rp, ip]
         L.oracle_av_velocity.restype = creal
@@ -105,6 +108,13 @@ class Oracle:
 
     def timestep(self, p, src, dst, obstacles):
         return float(self.lib.oracle_timestep(ctypes.byref(p), src, dst, obstacles))
+
+    def accelerate_row(self, p, cells, obstacles, row):
+        self.lib.oracle_accelerate_row(ctypes.byref(p), cells, obstacles, row)
+
+    def timestep_rows(self, p, src, dst, obstacles, y0, y1):
+        """rows [y0, y1) only; returns the raw sum of |j|/rho over their fluid cells"""
+        return float(self.lib.oracle_timestep_rows(ctypes.byref(p), src, dst, obstacles, y0, y1))
 
     def run(self, p, cells, obstacles, nsteps):
         """nsteps of accelerate+timestep in place on `cells`; returns av_vels[nsteps]."""
