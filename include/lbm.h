@@ -125,6 +125,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  * Tuning knobs (all optional; defaults are the measured-best on MI355X):
  *   "variant"      how a thread gets its x-1/x+1 neighbours: 0 = auto, 1 = scalar L1 loads,
  *                  2 = unaligned 16-byte loads, 3 = wave64 DPP shifts, 4 = LDS-staged row with halo
+ *   "fuse"         1 = advance two timesteps per launch (intermediate state kept in registers, half
+ *                  the HBM traffic), 0 = one launch per step, -1 = auto.  Single-slab grids only.
+ *   "chunk_rows"   rows swept by one wave of the two-step kernel (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)
  *   "nt_stores"    1 = non-temporal stores for the destination grid, 0 = plain, -1 = auto
  *   "use_graph"    1 = replay the step loop from a hipGraph, 0 = eager launches, -1 = auto

@@ -77,6 +77,10 @@ __device__ __forceinline__ void store4(float *p, float a, float b, float c, floa
 //  - eq_k = w_k*(rho + 3 j_k + (1.5/rho)(3 j_k^2 - j^2)) regrouped around the shared term
 //    c = rho - (1.5/rho) j^2.
 __device__ __forceinline__ float collide_cell(const float (&g)[9], bool obstacle, float omega, float (&out)[9]) {
+  // Every multiply-add below is spelled out (explicit fmaf, contraction off) so that all kernels that
+  // inline this function — one step per launch, two steps per launch, any load mode — round identically:
+  // their results are bit-for-bit equal whatever the surrounding code lets the compiler fuse.
+#pragma clang fp contract(off)
   const float w0 = 4.0f / 9.0f, w1 = 1.0f / 9.0f, w2 = 1.0f / 36.0f;
   float dens = g[0] + g[1];
   dens += g[2]; dens += g[3]; dens += g[4]; dens += g[5]; dens += g[6]; dens += g[7]; dens += g[8];
@@ -84,39 +88,40 @@ __device__ __forceinline__ float collide_cell(const float (&g)[9], bool obstacle
   const float da = g[5] - g[7], db = g[8] - g[6];
   const float jx = (g[1] - g[3]) + (da + db);
   const float jy = (g[2] - g[4]) + (da - db);
-  const float usq = jx * jx + jy * jy;
-  const float h = 1.5f * densinv;           // 0.5 * densinv * ic_sq
-  const float c = dens - h * usq;           // shared by all nine equilibria
+  const float usq = __builtin_fmaf(jx, jx, jy * jy);
+  const float h = 1.5f * densinv;                     // 0.5 * densinv * ic_sq
+  const float c = __builtin_fmaf(-h, usq, dens);      // rho - (1.5/rho) j^2, shared by all nine equilibria
   const float h3 = 3.0f * h;
   const float jp = jx + jy, jm = jx - jy;
-  const float ax = c + h3 * jx * jx, ay = c + h3 * jy * jy;
-  const float ap = c + h3 * jp * jp, am = c + h3 * jm * jm;
+  const float ax = __builtin_fmaf(h3 * jx, jx, c), ay = __builtin_fmaf(h3 * jy, jy, c);
+  const float ap = __builtin_fmaf(h3 * jp, jp, c), am = __builtin_fmaf(h3 * jm, jm, c);
   float eq[9];
   eq[0] = w0 * c;
-  eq[1] = w1 * (ax + 3.0f * jx);
-  eq[3] = w1 * (ax - 3.0f * jx);
-  eq[2] = w1 * (ay + 3.0f * jy);
-  eq[4] = w1 * (ay - 3.0f * jy);
-  eq[5] = w2 * (ap + 3.0f * jp);
-  eq[7] = w2 * (ap - 3.0f * jp);
-  eq[8] = w2 * (am + 3.0f * jm);
-  eq[6] = w2 * (am - 3.0f * jm);
-  // fluid: relax towards equilibrium; obstacle: the un-relaxed value leaves through the opposite
-  // speed (kernels.cl:69 lookup table: 0<->0, 1<->3, 2<->4, 5<->7, 6<->8)
-  out[0] = obstacle ? g[0] : g[0] + omega * (eq[0] - g[0]);
-  out[1] = obstacle ? g[3] : g[1] + omega * (eq[1] - g[1]);
-  out[2] = obstacle ? g[4] : g[2] + omega * (eq[2] - g[2]);
-  out[3] = obstacle ? g[1] : g[3] + omega * (eq[3] - g[3]);
-  out[4] = obstacle ? g[2] : g[4] + omega * (eq[4] - g[4]);
-  out[5] = obstacle ? g[7] : g[5] + omega * (eq[5] - g[5]);
-  out[6] = obstacle ? g[8] : g[6] + omega * (eq[6] - g[6]);
-  out[7] = obstacle ? g[5] : g[7] + omega * (eq[7] - g[7]);
-  out[8] = obstacle ? g[6] : g[8] + omega * (eq[8] - g[8]);
+  eq[1] = w1 * __builtin_fmaf(3.0f, jx, ax);
+  eq[3] = w1 * __builtin_fmaf(-3.0f, jx, ax);
+  eq[2] = w1 * __builtin_fmaf(3.0f, jy, ay);
+  eq[4] = w1 * __builtin_fmaf(-3.0f, jy, ay);
+  eq[5] = w2 * __builtin_fmaf(3.0f, jp, ap);
+  eq[7] = w2 * __builtin_fmaf(-3.0f, jp, ap);
+  eq[8] = w2 * __builtin_fmaf(3.0f, jm, am);
+  eq[6] = w2 * __builtin_fmaf(-3.0f, jm, am);
+  // fluid: relax towards equilibrium, f + omega*(eq - f); obstacle: the un-relaxed value leaves through
+  // the opposite speed (kernels.cl:69 lookup table: 0<->0, 1<->3, 2<->4, 5<->7, 6<->8)
+  out[0] = obstacle ? g[0] : __builtin_fmaf(omega, eq[0] - g[0], g[0]);
+  out[1] = obstacle ? g[3] : __builtin_fmaf(omega, eq[1] - g[1], g[1]);
+  out[2] = obstacle ? g[4] : __builtin_fmaf(omega, eq[2] - g[2], g[2]);
+  out[3] = obstacle ? g[1] : __builtin_fmaf(omega, eq[3] - g[3], g[3]);
+  out[4] = obstacle ? g[2] : __builtin_fmaf(omega, eq[4] - g[4], g[4]);
+  out[5] = obstacle ? g[7] : __builtin_fmaf(omega, eq[5] - g[5], g[5]);
+  out[6] = obstacle ? g[8] : __builtin_fmaf(omega, eq[6] - g[6], g[6]);
+  out[7] = obstacle ? g[5] : __builtin_fmaf(omega, eq[7] - g[7], g[7]);
+  out[8] = obstacle ? g[6] : __builtin_fmaf(omega, eq[8] - g[8], g[8]);
   return obstacle ? 0.0f : __builtin_amdgcn_sqrtf(usq) * densinv;
 }
 
 // accelerate_flow on one cell held in registers (kernels.cl:24-42)
 __device__ __forceinline__ void accelerate_cell(float (&f)[9], bool obstacle, float aw1, float aw2) {
+#pragma clang fp contract(off)
   if (!obstacle && (f[3] - aw1) > 0.0f && (f[6] - aw2) > 0.0f && (f[7] - aw2) > 0.0f) {
     f[1] += aw1; f[5] += aw2; f[8] += aw2;
     f[3] -= aw1; f[6] -= aw2; f[7] -= aw2;
@@ -317,12 +322,197 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
   block_store_partial(tot_u, a.partials);
 }
 
+// ---- two timesteps per launch (temporal blocking) ------------------------------------------------
+// One wave64 = one work unit: a strip of 64 float4-lanes sweeping `chunk_rows` grid rows upward.  Per
+// row it (1) gathers the source rows and collides once (the intermediate state I, step t+1) and keeps I
+// in REGISTERS — every value of I has exactly one consumer, and that consumer is this lane or the lane
+// next to it — then (2) gathers from I (own registers for the y-shifts, wave64 DPP for the x-shifts),
+// collides again (step t+2) and stores.  The grid is read once and written once per TWO steps:
+// ~38 B instead of 72 B of HBM traffic per lattice update.  Lane 0 and the lane after the strip's last
+// output lane are halo lanes: they compute I for the neighbouring strips' edge cells (redundantly) and
+// produce no output, so waves never communicate: no LDS, no barrier, no atomics.  Redundant work: 2 of
+// <= 64 lanes per row, 2 of chunk_rows+2 rows per unit.
+// Rows and columns wrap periodically (kernels.cl:91-102); used for a grid held by one slab.
+struct Step2Args {
+  const float *src;
+  float *dst;
+  const uint8_t *mask;
+  float *partials1;  // [units] sum of |j|/rho of step t+1 over the unit's owned cells
+  float *partials2;  // [units] same for step t+2
+  unsigned long long plane_stride, row_stride;
+  int nx, ny;
+  int strips, lanes_out;       // strips per row; output lanes per strip (<= 62); lane l owns float4 column s*lanes_out + l-1
+  int chunk_rows, nchunks;     // rows per unit; units = strips * nchunks
+  int accel_row;               // row ny-2
+  int accel_next;              // apply the following step's accelerate_flow to the output row ny-2
+  float omega, aw1, aw2;
+};
+
+struct RowLoads {
+  float4 c[9];
+  float h0, h1, h2;  // halo elements (lane 0: west of planes 1,5,8; last lane: east of planes 3,6,7)
+  uint32_t m;
+};
+
+__device__ __forceinline__ void issue_row_loads(const Step2Args &a, int r, int xcol, int xhalo_w, int xhalo_e, int lane,
+                                                RowLoads &in) {
+  const size_t ps = a.plane_stride, rs = a.row_stride;
+  const int r_s = (r == 0) ? a.ny - 1 : r - 1;
+  const int r_n = (r == a.ny - 1) ? 0 : r + 1;
+  const float *Rc = a.src + (size_t)r * rs, *Rs = a.src + (size_t)r_s * rs, *Rn = a.src + (size_t)r_n * rs;
+  in.c[0] = *reinterpret_cast<const float4 *>(Rc + xcol);
+  in.c[1] = *reinterpret_cast<const float4 *>(Rc + 1 * ps + xcol);
+  in.c[3] = *reinterpret_cast<const float4 *>(Rc + 3 * ps + xcol);
+  in.c[2] = *reinterpret_cast<const float4 *>(Rs + 2 * ps + xcol);
+  in.c[5] = *reinterpret_cast<const float4 *>(Rs + 5 * ps + xcol);
+  in.c[6] = *reinterpret_cast<const float4 *>(Rs + 6 * ps + xcol);
+  in.c[4] = *reinterpret_cast<const float4 *>(Rn + 4 * ps + xcol);
+  in.c[7] = *reinterpret_cast<const float4 *>(Rn + 7 * ps + xcol);
+  in.c[8] = *reinterpret_cast<const float4 *>(Rn + 8 * ps + xcol);
+  in.m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)r * a.nx + xcol);
+  in.h0 = in.h1 = in.h2 = 0.f;
+  if (lane == 0 || lane == 63) {
+    const bool lo = (lane == 0);
+    in.h0 = lo ? Rc[1 * ps + xhalo_w] : Rc[3 * ps + xhalo_e];
+    in.h1 = lo ? Rs[5 * ps + xhalo_w] : Rs[6 * ps + xhalo_e];
+    in.h2 = lo ? Rn[8 * ps + xhalo_w] : Rn[7 * ps + xhalo_e];
+  }
+}
+
+// shifts a float4-per-lane plane by one cell: result[v] = value at x-1 (west) or x+1 (east)
+__device__ __forceinline__ void shift_from_west(const float (&p)[4], float halo, float (&out)[4]) {
+  out[0] = dpp_from_lane_below(p[3], halo); out[1] = p[0]; out[2] = p[1]; out[3] = p[2];
+}
+__device__ __forceinline__ void shift_from_east(const float (&p)[4], float halo, float (&out)[4]) {
+  out[0] = p[1]; out[1] = p[2]; out[2] = p[3]; out[3] = dpp_from_lane_above(p[0], halo);
+}
+
+__device__ __forceinline__ void unpack4(const float4 &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+
+// gathered distributions g[k][v] -> collided cell values o[k][v]; returns the sum of |j|/rho of the 4 cells
+__device__ __forceinline__ float collide4(const float (&g)[9][4], uint32_t m, float omega, bool accel, float aw1, float aw2,
+                                          float (&o)[9][4]) {
+  float tot = 0.f;
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const bool obst = ((m >> (8 * v)) & 0xffu) != 0;
+    float gc[9], oc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) gc[k] = g[k][v];
+    tot += collide_cell(gc, obst, omega, oc);
+    if (accel) accelerate_cell(oc, obst, aw1, aw2);
+#pragma unroll
+    for (int k = 0; k < 9; k++) o[k][v] = oc[k];
+  }
+  return tot;
+}
+
+// step t+1 of one row from the loaded source values
+__device__ __forceinline__ float first_step_row(const Step2Args &a, const RowLoads &in, int r, float (&I)[9][4]) {
+  float g[9][4], c[4];
+  unpack4(in.c[0], g[0]); unpack4(in.c[2], g[2]); unpack4(in.c[4], g[4]);
+  unpack4(in.c[1], c); shift_from_west(c, in.h0, g[1]);
+  unpack4(in.c[5], c); shift_from_west(c, in.h1, g[5]);
+  unpack4(in.c[8], c); shift_from_west(c, in.h2, g[8]);
+  unpack4(in.c[3], c); shift_from_east(c, in.h0, g[3]);
+  unpack4(in.c[6], c); shift_from_east(c, in.h1, g[6]);
+  unpack4(in.c[7], c); shift_from_east(c, in.h2, g[7]);
+  // the intermediate row ny-2 receives step t+2's accelerate_flow before it is streamed (kernels.cl:9-53)
+  return collide4(g, in.m, a.omega, r == a.accel_row, a.aw1, a.aw2, I);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
+  const int lane = threadIdx.x;
+  const int unit = blockIdx.x;
+  const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
+  const int ys = chunk * a.chunk_rows;
+  const int ye = min(ys + a.chunk_rows, a.ny);
+  const int q4 = a.nx >> 2;                              // float4 columns per row
+  const int qcol = strip * a.lanes_out + lane - 1;        // this lane's float4 column, unwrapped
+  const bool owner = (lane >= 1) && (lane <= a.lanes_out) && (qcol < q4);
+  int qw = qcol % q4;
+  if (qw < 0) qw += q4;
+  const int xcol = qw * 4;
+  const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
+  const int xhalo_e = (xcol + 4 >= a.nx) ? 0 : xcol + 4;
+  const size_t ps = a.plane_stride;
+  auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
+
+  float sum1 = 0.f, sum2 = 0.f;
+  float low[3][4];   // planes 2,5,6 of I(row-2 relative to top)
+  float mid[6][4];   // planes 0,1,3,2,5,6 of I(row-1)
+  float top[9][4];   // I(row)
+  uint32_t m_mid, m_top;
+  RowLoads in;
+  {
+    float I[9][4];
+    const int r0 = wrap(ys - 1);
+    issue_row_loads(a, r0, xcol, xhalo_w, xhalo_e, lane, in);
+    first_step_row(a, in, r0, I);  // row below the chunk: owned by the neighbouring unit, not summed
+#pragma unroll
+    for (int v = 0; v < 4; v++) { low[0][v] = I[2][v]; low[1][v] = I[5][v]; low[2][v] = I[6][v]; }
+    issue_row_loads(a, ys, xcol, xhalo_w, xhalo_e, lane, in);
+    const float t = first_step_row(a, in, ys, I);
+    if (owner) sum1 += t;
+    m_mid = in.m;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      mid[0][v] = I[0][v]; mid[1][v] = I[1][v]; mid[2][v] = I[3][v];
+      mid[3][v] = I[2][v]; mid[4][v] = I[5][v]; mid[5][v] = I[6][v];
+    }
+  }
+  issue_row_loads(a, wrap(ys + 1), xcol, xhalo_w, xhalo_e, lane, in);
+  for (int j = ys + 1; j <= ye; j++) {
+    // intermediate row j (the last one, j == ye, belongs to the next chunk: computed, not summed)
+    const int rj = wrap(j);
+    const float t1 = first_step_row(a, in, rj, top);
+    m_top = in.m;
+    if (owner && j < ye) sum1 += t1;
+    if (j < ye) issue_row_loads(a, wrap(j + 1), xcol, xhalo_w, xhalo_e, lane, in);  // in flight during the second step
+    // step t+2 of row j-1: y-shifted values come from this lane's own registers, x-shifted ones by DPP
+    {
+      const int y = j - 1;
+      float g[9][4], o[9][4];
+#pragma unroll
+      for (int v = 0; v < 4; v++) { g[0][v] = mid[0][v]; g[2][v] = low[0][v]; g[4][v] = top[4][v]; }
+      shift_from_west(mid[1], 0.f, g[1]);
+      shift_from_east(mid[2], 0.f, g[3]);
+      shift_from_west(low[1], 0.f, g[5]);
+      shift_from_east(low[2], 0.f, g[6]);
+      shift_from_east(top[7], 0.f, g[7]);
+      shift_from_west(top[8], 0.f, g[8]);
+      const float t2 = collide4(g, m_mid, a.omega, (y == a.accel_row) && a.accel_next, a.aw1, a.aw2, o);
+      if (owner) {
+        sum2 += t2;
+        float *d = a.dst + (size_t)y * a.row_stride + xcol;
+#pragma unroll
+        for (int k = 0; k < 9; k++) store4<NT>(d + k * ps, o[k][0], o[k][1], o[k][2], o[k][3]);
+      }
+    }
+    // rotate the register window one row up
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      low[0][v] = mid[3][v]; low[1][v] = mid[4][v]; low[2][v] = mid[5][v];
+      mid[0][v] = top[0][v]; mid[1][v] = top[1][v]; mid[2][v] = top[3][v];
+      mid[3][v] = top[2][v]; mid[4][v] = top[5][v]; mid[5][v] = top[6][v];
+    }
+    m_mid = m_top;
+  }
+  sum1 = wave_sum(sum1);
+  sum2 = wave_sum(sum2);
+  if (lane == 0) {
+    a.partials1[unit] = sum1;
+    a.partials2[unit] = sum2;
+  }
+}
+
 // ---- second reduction stage ------------------------------------------------------------------
 // One workgroup per buffered step: sums that step's per-workgroup partials in a fixed order into
 // av_sum[first + blockIdx.x] (double).  Replaces the reference's multi-pass reduce kernel
 // (kernels.cl:234-290) and its in-place pass results.
-__global__ __launch_bounds__(kBlock) void reduce_partials(const float *partials, int nb, double *av_sum) {
-  const float *p = partials + (size_t)blockIdx.x * nb;
+__global__ __launch_bounds__(kBlock) void reduce_partials(const float *partials, int stride, int nb, double *av_sum) {
+  const float *p = partials + (size_t)blockIdx.x * stride;
   double acc = 0.0;
   for (int i = threadIdx.x; i < nb; i += kBlock) acc += (double)p[i];
   __shared__ double wsum[kBlock / 64];

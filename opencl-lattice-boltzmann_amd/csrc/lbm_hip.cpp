@@ -112,7 +112,8 @@ struct Slab {
   float *halo_send[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   float *halo_recv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   float *partials = nullptr;  // [ring][nb_total]
-  int nb_main = 0, nb_edge = 0, nb_total = 0;
+  int nb_main = 0, nb_edge = 0, nb_total = 0;  // workgroups of the interior / edge launch; slot stride of the ring
+  int f_strips = 0, f_lanes = 0, f_chunk = 0, f_nchunks = 0, f_units = 0;  // geometry of d2q9_step2
   double *av_sum = nullptr;   // [capacity] per-step sum of |j|/rho over this slab's fluid cells
   hipStream_t s_main = nullptr, s_edge = nullptr;
   hipEvent_t ev_main[2] = {nullptr, nullptr};   // interior kernel of a step done
@@ -144,6 +145,8 @@ struct lbm_ctx {
   int grid_blocks = 0;
   int nt_stores = -1;
   int use_graph = -1;
+  int fuse = -1;            // two timesteps per launch (d2q9_step2): -1 auto, 0 off, 1 on
+  int chunk_rows = 0;       // rows per work unit of d2q9_step2 (0 = auto)
   bool vec4 = true;
   double *av_host = nullptr;  // staging for downloads
 };
@@ -175,6 +178,24 @@ int step_blocks(const lbm_ctx *c, int work_rows) {
   int nb = div_up(threads, kBlock);
   if (c->grid_blocks > 0) nb = std::min(nb, c->grid_blocks);
   return std::max(1, nb);
+}
+
+// two-steps-per-launch kernel: usable when one slab holds the whole (periodic) grid
+bool fuse_possible(const lbm_ctx *c) {
+  return c->nslabs_global == 1 && c->vec4 && c->p.nx >= 256 && c->p.ny >= 8;
+}
+bool fuse_effective(const lbm_ctx *c) {
+  if (!fuse_possible(c)) return false;
+  return c->fuse != 0;
+}
+void fuse_geometry(const lbm_ctx *c, Slab &s) {
+  const int q4 = c->p.nx / 4;
+  s.f_strips = div_up(q4, 62);             // lanes 0 and 63 of every wave are halo lanes
+  s.f_lanes = div_up(q4, s.f_strips);
+  s.f_chunk = c->chunk_rows > 0 ? c->chunk_rows : 32;
+  s.f_chunk = std::max(2, std::min(s.f_chunk, s.rows));
+  s.f_nchunks = div_up(s.rows, s.f_chunk);
+  s.f_units = s.f_strips * s.f_nchunks;
 }
 
 bool nt_effective(const lbm_ctx *c) {
@@ -310,23 +331,89 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     }
 
   int batch_first = c->steps_done;
-  for (int i = 0; i < nsteps; i++) {
-    const bool last = (i == nsteps - 1);
-    const int q = i & 1, qp = q ^ 1;  // parity of this step / of the previous one (initial state = 1)
-    const int src = c->cur;
-    if (!multi) {
-      Slab &s = c->slabs[0];
-      StepArgs a = base_args(c, s, src, !last);
-      for (int k = 0; k < 3; k++) {
-        static const int sp[3] = {2, 5, 6}, np[3] = {4, 7, 8};
-        a.south_src[k] = s.cells[src] + sp[k] * s.plane_stride + (size_t)(s.rows - 1) * s.row_stride;  // y wrap (kernels.cl:91-93)
-        a.north_src[k] = s.cells[src] + np[k] * s.plane_stride;
-      }
-      a.y_begin = 0; a.y_count = s.rows; a.y_step = 1;
-      a.partials = s.partials + (size_t)c->ring_fill * s.nb_total;
-      launch_step(c, a, s.nb_main, s.s_main);
+  int batch_nb = 0;  // partial sums per slot in the current batch (differs between launch kinds)
+  // second reduction stage over the buffered steps of all slabs (kernels.cl:234-290 counterpart)
+  auto flush = [&](int lastq) -> int {
+    const int fill = c->ring_fill;
+    if (fill == 0) return LBM_OK;
+    for (Slab &s : c->slabs) {
+      if (set_dev(s)) return LBM_ERR_HIP;
+      if (multi) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[lastq], 0));
+      hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total,
+                         multi ? s.nb_total : batch_nb, s.av_sum + batch_first);
       HIP_TRY(hipGetLastError());
-    } else {
+      if (multi) {
+        // the next batch's edge kernels overwrite ring slots: order them after this reduction
+        HIP_TRY(hipEventRecord(s.ev_aux, s.s_main));
+        HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_aux, 0));
+      }
+    }
+    batch_first += fill;
+    c->ring_fill = 0;
+    return LBM_OK;
+  };
+
+  if (!multi) {
+    Slab &s = c->slabs[0];
+    const bool fuse = fuse_effective(c);
+    int i = 0;
+    while (i < nsteps) {
+      const int src = c->cur;
+      if (fuse && nsteps - i >= 2) {
+        // steps i and i+1 in one pass over the grid
+        if (batch_nb != s.f_units || c->ring_fill + 2 > c->ring)
+          if (int rc = flush(0)) return rc;
+        batch_nb = s.f_units;
+        Step2Args a{};
+        a.src = s.cells[src];
+        a.dst = s.cells[src ^ 1];
+        a.mask = s.mask;
+        a.partials1 = s.partials + (size_t)c->ring_fill * s.nb_total;
+        a.partials2 = s.partials + (size_t)(c->ring_fill + 1) * s.nb_total;
+        a.plane_stride = s.plane_stride;
+        a.row_stride = s.row_stride;
+        a.nx = nx;
+        a.ny = s.rows;
+        a.strips = s.f_strips;
+        a.lanes_out = s.f_lanes;
+        a.chunk_rows = s.f_chunk;
+        a.nchunks = s.f_nchunks;
+        a.accel_row = s.accel_row;
+        a.accel_next = (i + 2 < nsteps) ? 1 : 0;
+        a.omega = c->p.omega;
+        a.aw1 = aw1;
+        a.aw2 = aw2;
+        if (nt_effective(c)) hipLaunchKernelGGL((d2q9_step2<true>), dim3(s.f_units), dim3(64), 0, s.s_main, a);
+        else hipLaunchKernelGGL((d2q9_step2<false>), dim3(s.f_units), dim3(64), 0, s.s_main, a);
+        HIP_TRY(hipGetLastError());
+        c->ring_fill += 2;
+        i += 2;
+      } else {
+        if (batch_nb != s.nb_main || c->ring_fill + 1 > c->ring)
+          if (int rc = flush(0)) return rc;
+        batch_nb = s.nb_main;
+        const bool last = (i == nsteps - 1);
+        StepArgs a = base_args(c, s, src, !last);
+        for (int k = 0; k < 3; k++) {
+          static const int sp[3] = {2, 5, 6}, np[3] = {4, 7, 8};
+          a.south_src[k] = s.cells[src] + sp[k] * s.plane_stride + (size_t)(s.rows - 1) * s.row_stride;  // y wrap (kernels.cl:91-93)
+          a.north_src[k] = s.cells[src] + np[k] * s.plane_stride;
+        }
+        a.y_begin = 0; a.y_count = s.rows; a.y_step = 1;
+        a.partials = s.partials + (size_t)c->ring_fill * s.nb_total;
+        launch_step(c, a, s.nb_main, s.s_main);
+        HIP_TRY(hipGetLastError());
+        c->ring_fill += 1;
+        i += 1;
+      }
+      c->cur ^= 1;
+    }
+    if (int rc = flush(0)) return rc;
+  } else {
+    for (int i = 0; i < nsteps; i++) {
+      const bool last = (i == nsteps - 1);
+      const int q = i & 1, qp = q ^ 1;  // parity of this step / of the previous one (initial state = 1)
+      const int src = c->cur;
       for (Slab &s : c->slabs) {
         if (set_dev(s)) return LBM_ERR_HIP;
         float *part = s.partials + (size_t)c->ring_fill * s.nb_total;
@@ -360,27 +447,10 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       }
       if (!last)
         if (int rc = exchange_halos(c, q)) return rc;
-    }
-    c->cur ^= 1;
-    c->ring_fill++;
-    if (c->ring_fill == c->ring || last) {
-      // flush_ring needs the parity of the last edge kernel
-      const int lastq = q;
-      const int fill = c->ring_fill;
-      for (Slab &s : c->slabs) {
-        if (set_dev(s)) return LBM_ERR_HIP;
-        if (multi) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[lastq], 0));
-        hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total,
-                           s.av_sum + batch_first);
-        HIP_TRY(hipGetLastError());
-        if (multi) {
-          // the next batch's edge kernels overwrite ring slots: order them after this reduction
-          HIP_TRY(hipEventRecord(s.ev_aux, s.s_main));
-          HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_aux, 0));
-        }
-      }
-      batch_first += fill;
-      c->ring_fill = 0;
+      c->cur ^= 1;
+      c->ring_fill++;
+      if (c->ring_fill == c->ring || last)
+        if (int rc = flush(q)) return rc;
     }
   }
   c->steps_done += nsteps;
@@ -488,6 +558,10 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
     s.nb_edge = 0;
   }
   s.nb_total = s.nb_main + s.nb_edge;
+  if (fuse_possible(c)) {
+    fuse_geometry(c, s);
+    s.nb_total = std::max(s.nb_total, s.f_units);
+  }
   if (dev_alloc(&s.av_sum, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
   s.fin_blocks = std::max(1, std::min(div_up((long)n, kBlock), 2048));
   if (dev_alloc(&s.fin_partials, (size_t)s.fin_blocks)) return LBM_ERR_HIP;
@@ -529,6 +603,10 @@ int rebuild_geometry(lbm_ctx *c) {
       s.nb_edge = 0;
     }
     s.nb_total = s.nb_main + s.nb_edge;
+    if (fuse_possible(c)) {
+      fuse_geometry(c, s);
+      s.nb_total = std::max(s.nb_total, s.f_units);
+    }
   }
   return alloc_partials(c);
 }
@@ -845,6 +923,13 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     return rebuild_geometry(c);
   }
   if (!strcmp(key, "nt_stores")) { c->nt_stores = (int)value; return LBM_OK; }
+  if (!strcmp(key, "fuse")) { c->fuse = (int)value; return LBM_OK; }
+  if (!strcmp(key, "chunk_rows")) {
+    if (value < 0) return fail(LBM_ERR_ARG, "chunk_rows must be >= 0");
+    if (int rc = sync_all(c)) return rc;
+    c->chunk_rows = (int)value;
+    return rebuild_geometry(c);
+  }
   if (!strcmp(key, "use_graph")) { c->use_graph = (int)value; return LBM_OK; }
   if (!strcmp(key, "transport")) { c->transport = (int)value; return LBM_OK; }
   return fail(LBM_ERR_ARG, "unknown option '%s'", key);
@@ -855,6 +940,8 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   if (!strcmp(key, "variant")) *value = effective_mode(c) + 1;
   else if (!strcmp(key, "grid_blocks")) *value = c->slabs.empty() ? 0 : c->slabs[0].nb_main;
   else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
+  else if (!strcmp(key, "fuse")) *value = fuse_effective(c);
+  else if (!strcmp(key, "chunk_rows")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_chunk;
   else if (!strcmp(key, "use_graph")) *value = c->use_graph;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;

@@ -86,6 +86,32 @@ def test_all_load_variants_agree_bitwise(lbm, oracle_f32, variant, nt):
     assert max_rel(got, ref) < RTOL_CELLS and max_rel(av, av_ref) < RTOL_AV
 
 
+@pytest.mark.parametrize("nx,ny,chunk", [(256, 8, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (2048, 16, 16), (260, 33, 4),
+                                         (8192, 24, 8)])
+@pytest.mark.parametrize("nsteps", [2, 3, 9])
+def test_two_steps_per_launch_equals_single_steps(lbm, oracle_f32_omp, nx, ny, chunk, nsteps):
+    """d2q9_step2 (two timesteps per launch, intermediate state in registers) performs the same per-cell
+    arithmetic as two launches of d2q9_step: the states must agree bit for bit, av_vels up to summation
+    order; odd step counts end with one single-step launch; both agree with the oracle"""
+    rng = np.random.default_rng(nx + 7 * ny + nsteps)
+    ob, cells0 = random_case(rng, nx, ny)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 0})
+    with lbm.LBM(p, ob) as sim:
+        sim.set_option("fuse", 1)
+        sim.set_option("chunk_rows", chunk)
+        assert sim.get_option("fuse") == 1
+        sim.upload(cells0)
+        sim.run(nsteps)
+        fused, av_fused = sim.download()
+    assert np.array_equal(fused, single)
+    assert max_rel(av_fused, av_single) < 2e-6
+    po = oracle_params(oracle_f32_omp, p, ob)
+    ref = cells0.copy()
+    av_ref = oracle_f32_omp.run(po, ref, ob, nsteps)
+    assert max_rel(fused, ref) < RTOL_CELLS and max_rel(av_fused, av_ref) < RTOL_AV
+
+
 @pytest.mark.parametrize("nx,ny", [(3, 3), (5, 4), (30, 17), (132, 40), (256, 3), (260, 7), (1024, 5), (64, 300)])
 def test_ragged_sizes(lbm, oracle_f32, nx, ny):
     """nx not a multiple of 4 (scalar kernel), of 256 (no wave-level modes), tiny and thin grids;
