@@ -127,7 +127,8 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  2 = unaligned 16-byte loads, 3 = wave64 DPP shifts, 4 = LDS-staged row with halo
  *   "fuse"         1 = advance two timesteps per launch (intermediate state kept in registers, half
  *                  the HBM traffic), 0 = one launch per step, -1 = auto.  Single-slab grids only.
- *   "chunk_rows"   rows swept by one wave of the two-step kernel (0 = auto)
+ *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)
+ *   "chunk_min"    fewest rows per wave at the tapered end of the schedule (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)
  *   "nt_stores"    1 = non-temporal stores for the destination grid, 0 = plain, -1 = auto
  *   "use_graph"    1 = replay the step loop from a hipGraph, 0 = eager launches, -1 = auto

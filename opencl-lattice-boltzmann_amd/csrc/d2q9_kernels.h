@@ -76,11 +76,14 @@ __device__ __forceinline__ void store4(float *p, float a, float b, float c, floa
 //  - momenta from pairwise differences (a cell at rest has exactly zero momentum in fp32),
 //  - eq_k = w_k*(rho + 3 j_k + (1.5/rho)(3 j_k^2 - j^2)) regrouped around the shared term
 //    c = rho - (1.5/rho) j^2.
-__device__ __forceinline__ float collide_cell(const float (&g)[9], bool obstacle, float omega, float (&out)[9]) {
+template <bool MAY_BE_OBSTACLE = true>
+__device__ __forceinline__ float collide_cell(const float (&g)[9], bool obstacle_in, float omega, float (&out)[9]) {
+  // MAY_BE_OBSTACLE = false: the caller knows no cell of the wave is blocked; the bounce-back selects vanish
   // Every multiply-add below is spelled out (explicit fmaf, contraction off) so that all kernels that
   // inline this function — one step per launch, two steps per launch, any load mode — round identically:
   // their results are bit-for-bit equal whatever the surrounding code lets the compiler fuse.
 #pragma clang fp contract(off)
+  const bool obstacle = MAY_BE_OBSTACLE && obstacle_in;
   const float w0 = 4.0f / 9.0f, w1 = 1.0f / 9.0f, w2 = 1.0f / 36.0f;
   float dens = g[0] + g[1];
   dens += g[2]; dens += g[3]; dens += g[4]; dens += g[5]; dens += g[6]; dens += g[7]; dens += g[8];
@@ -141,6 +144,37 @@ __device__ __forceinline__ void block_store_partial(float v, float *partials) {
   }
 }
 
+// gathered distributions g[k][v] -> collided cell values o[k][v]; returns the sum of |j|/rho of the 4 cells
+__device__ __forceinline__ float collide4(const float (&g)[9][4], uint32_t m, float omega, bool accel, float aw1, float aw2,
+                                          float (&o)[9][4]) {
+  float tot = 0.f;
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const bool obst = ((m >> (8 * v)) & 0xffu) != 0;
+    float gc[9], oc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) gc[k] = g[k][v];
+    tot += collide_cell<true>(gc, obst, omega, oc);
+#pragma unroll
+    for (int k = 0; k < 9; k++) o[k][v] = oc[k];
+  }
+  // accelerate_flow touches one row of the grid: keep it out of the instruction stream of all other rows
+  // (a real scalar branch on "any lane of the wave is on that row" instead of predicated code on every cell)
+  if (__builtin_amdgcn_readfirstlane((int)(__ballot(accel) != 0ull))) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const bool obst = ((m >> (8 * v)) & 0xffu) != 0;
+      float oc[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) oc[k] = o[k][v];
+      if (accel) accelerate_cell(oc, obst, aw1, aw2);  // a wave may straddle two rows when nx/4 is not a multiple of 64
+#pragma unroll
+      for (int k = 0; k < 9; k++) o[k][v] = oc[k];
+    }
+  }
+  return tot;
+}
+
 // ---- the step kernel ---------------------------------------------------------------------------
 // How a thread obtains the x-1 / x+1 neighbours of its four cells (planes 1,5,8 stream from the
 // west, 3,6,7 from the east).  HBM traffic is identical in all modes — 9 floats in + 9 floats out
@@ -195,6 +229,7 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
 
     float g[9][VEC];
     bool obst[VEC];
+    uint32_t mask_word = 0;
     if constexpr (VEC == 4) {
       // all loads are issued before any use
       const float4 c0 = *reinterpret_cast<const float4 *>(rc + x0);
@@ -204,6 +239,7 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
       g[0][0] = c0.x; g[0][1] = c0.y; g[0][2] = c0.z; g[0][3] = c0.w;
       g[2][0] = c2.x; g[2][1] = c2.y; g[2][2] = c2.z; g[2][3] = c2.w;
       g[4][0] = c4.x; g[4][1] = c4.y; g[4][2] = c4.z; g[4][3] = c4.w;
+      mask_word = m;
       obst[0] = (m & 0xffu) != 0; obst[1] = (m & 0xff00u) != 0;
       obst[2] = (m & 0xff0000u) != 0; obst[3] = (m & 0xff000000u) != 0;
       if constexpr (LM == LM_UNALIGNED) {
@@ -283,15 +319,16 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
 
     float o[9][VEC];
     const bool accel_here = (y == a.accel_row);
-#pragma unroll
-    for (int v = 0; v < VEC; v++) {
+    if constexpr (VEC == 4) {
+      tot_u += collide4(g, mask_word, a.omega, accel_here, a.aw1, a.aw2, o);
+    } else {
       float gc[9], oc[9];
 #pragma unroll
-      for (int k = 0; k < 9; k++) gc[k] = g[k][v];
-      tot_u += collide_cell(gc, obst[v], a.omega, oc);
-      if (accel_here) accelerate_cell(oc, obst[v], a.aw1, a.aw2);
+      for (int k = 0; k < 9; k++) gc[k] = g[k][0];
+      tot_u += collide_cell(gc, obst[0], a.omega, oc);
+      if (accel_here) accelerate_cell(oc, obst[0], a.aw1, a.aw2);
 #pragma unroll
-      for (int k = 0; k < 9; k++) o[k][v] = oc[k];
+      for (int k = 0; k < 9; k++) o[k][0] = oc[k];
     }
 
     float *d = a.dst + row + x0;
@@ -342,7 +379,9 @@ struct Step2Args {
   unsigned long long plane_stride, row_stride;
   int nx, ny;
   int strips, lanes_out;       // strips per row; output lanes per strip (<= 62); lane l owns float4 column s*lanes_out + l-1
-  int chunk_rows, nchunks;     // rows per unit; units = strips * nchunks
+  const int *chunk_start;      // [nchunks+1] first row of every chunk (chunks get shorter towards the end of a band)
+  int nchunks;                 // units = strips * nchunks
+  int nbands, units_per_band;  // workgroup b works on unit (b % nbands)*units_per_band + b / nbands
   int accel_row;               // row ny-2
   int accel_next;              // apply the following step's accelerate_flow to the output row ny-2
   float omega, aw1, aw2;
@@ -389,24 +428,6 @@ __device__ __forceinline__ void shift_from_east(const float (&p)[4], float halo,
 
 __device__ __forceinline__ void unpack4(const float4 &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 
-// gathered distributions g[k][v] -> collided cell values o[k][v]; returns the sum of |j|/rho of the 4 cells
-__device__ __forceinline__ float collide4(const float (&g)[9][4], uint32_t m, float omega, bool accel, float aw1, float aw2,
-                                          float (&o)[9][4]) {
-  float tot = 0.f;
-#pragma unroll
-  for (int v = 0; v < 4; v++) {
-    const bool obst = ((m >> (8 * v)) & 0xffu) != 0;
-    float gc[9], oc[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) gc[k] = g[k][v];
-    tot += collide_cell(gc, obst, omega, oc);
-    if (accel) accelerate_cell(oc, obst, aw1, aw2);
-#pragma unroll
-    for (int k = 0; k < 9; k++) o[k][v] = oc[k];
-  }
-  return tot;
-}
-
 // step t+1 of one row from the loaded source values
 __device__ __forceinline__ float first_step_row(const Step2Args &a, const RowLoads &in, int r, float (&I)[9][4]) {
   float g[9][4], c[4];
@@ -424,10 +445,19 @@ __device__ __forceinline__ float first_step_row(const Step2Args &a, const RowLoa
 template <bool NT>
 __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   const int lane = threadIdx.x;
-  const int unit = blockIdx.x;
+  // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, MI355X_MICROARCH.md), so
+  // band (b % nbands) of contiguous units stays on one XCD: neighbouring strips and chunks — which
+  // re-read each other's edge lines and boundary rows — then share that XCD's L2.  Speed only.
+  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
+  if (slot >= a.units_per_band) return;
+  const int unit = band * a.units_per_band + slot;
   const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
-  const int ys = chunk * a.chunk_rows;
-  const int ye = min(ys + a.chunk_rows, a.ny);
+  const int ys = a.chunk_start[chunk];
+  const int ye = a.chunk_start[chunk + 1];
+  if (ys >= ye) {  // padding chunk of a short band
+    if (lane == 0) a.partials1[unit] = a.partials2[unit] = 0.f;
+    return;
+  }
   const int q4 = a.nx >> 2;                              // float4 columns per row
   const int qcol = strip * a.lanes_out + lane - 1;        // this lane's float4 column, unwrapped
   const bool owner = (lane >= 1) && (lane <= a.lanes_out) && (qcol < q4);
@@ -444,34 +474,28 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   float mid[6][4];   // planes 0,1,3,2,5,6 of I(row-1)
   float top[9][4];   // I(row)
   uint32_t m_mid, m_top;
-  RowLoads in;
-  {
-    float I[9][4];
-    const int r0 = wrap(ys - 1);
-    issue_row_loads(a, r0, xcol, xhalo_w, xhalo_e, lane, in);
-    first_step_row(a, in, r0, I);  // row below the chunk: owned by the neighbouring unit, not summed
+  // two row-sets of source loads are kept in flight (ping-pong) so that HBM latency is covered by
+  // both collision passes of an iteration
+  RowLoads inA, inB;
+  issue_row_loads(a, wrap(ys - 1), xcol, xhalo_w, xhalo_e, lane, inA);
+  issue_row_loads(a, ys, xcol, xhalo_w, xhalo_e, lane, inB);
 #pragma unroll
-    for (int v = 0; v < 4; v++) { low[0][v] = I[2][v]; low[1][v] = I[5][v]; low[2][v] = I[6][v]; }
-    issue_row_loads(a, ys, xcol, xhalo_w, xhalo_e, lane, in);
-    const float t = first_step_row(a, in, ys, I);
-    if (owner) sum1 += t;
-    m_mid = in.m;
+  for (int v = 0; v < 4; v++) {
+    low[0][v] = low[1][v] = low[2][v] = 0.f;
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-      mid[0][v] = I[0][v]; mid[1][v] = I[1][v]; mid[2][v] = I[3][v];
-      mid[3][v] = I[2][v]; mid[4][v] = I[5][v]; mid[5][v] = I[6][v];
-    }
+    for (int k = 0; k < 6; k++) mid[k][v] = 0.f;
   }
-  issue_row_loads(a, wrap(ys + 1), xcol, xhalo_w, xhalo_e, lane, in);
-  for (int j = ys + 1; j <= ye; j++) {
-    // intermediate row j (the last one, j == ye, belongs to the next chunk: computed, not summed)
-    const int rj = wrap(j);
-    const float t1 = first_step_row(a, in, rj, top);
+  m_mid = 0;
+  // one iteration: intermediate row j from `in` (then refill `in` with row j+2), output row j-1
+  auto iterate = [&](int j, RowLoads &in) {
+    // intermediate row j; rows ys-1 and ye belong to the neighbouring chunks: computed, not summed
+    const float t1 = first_step_row(a, in, wrap(j), top);
     m_top = in.m;
-    if (owner && j < ye) sum1 += t1;
-    if (j < ye) issue_row_loads(a, wrap(j + 1), xcol, xhalo_w, xhalo_e, lane, in);  // in flight during the second step
-    // step t+2 of row j-1: y-shifted values come from this lane's own registers, x-shifted ones by DPP
-    {
+    if (owner && j >= ys && j < ye) sum1 += t1;
+    if (j + 2 <= ye) issue_row_loads(a, wrap(j + 2), xcol, xhalo_w, xhalo_e, lane, in);
+    // step t+2 of row j-1 (needs intermediate rows j-2, j-1, j: from the third iteration on); y-shifted
+    // values come from this lane's own registers, x-shifted ones by DPP
+    if (j > ys) {
       const int y = j - 1;
       float g[9][4], o[9][4];
 #pragma unroll
@@ -498,6 +522,10 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
       mid[3][v] = top[2][v]; mid[4][v] = top[5][v]; mid[5][v] = top[6][v];
     }
     m_mid = m_top;
+  };
+  for (int j = ys - 1; j <= ye; j += 2) {
+    iterate(j, inA);
+    if (j + 1 <= ye) iterate(j + 1, inB);
   }
   sum1 = wave_sum(sum1);
   sum2 = wave_sum(sum2);

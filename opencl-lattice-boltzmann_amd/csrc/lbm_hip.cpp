@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -114,6 +115,8 @@ struct Slab {
   float *partials = nullptr;  // [ring][nb_total]
   int nb_main = 0, nb_edge = 0, nb_total = 0;  // workgroups of the interior / edge launch; slot stride of the ring
   int f_strips = 0, f_lanes = 0, f_chunk = 0, f_nchunks = 0, f_units = 0;  // geometry of d2q9_step2
+  int f_nbands = 1, f_units_per_band = 0, f_grid = 0;
+  int *f_chunk_start = nullptr;  // device copy of the chunk schedule
   double *av_sum = nullptr;   // [capacity] per-step sum of |j|/rho over this slab's fluid cells
   hipStream_t s_main = nullptr, s_edge = nullptr;
   hipEvent_t ev_main[2] = {nullptr, nullptr};   // interior kernel of a step done
@@ -146,7 +149,8 @@ struct lbm_ctx {
   int nt_stores = -1;
   int use_graph = -1;
   int fuse = -1;            // two timesteps per launch (d2q9_step2): -1 auto, 0 off, 1 on
-  int chunk_rows = 0;       // rows per work unit of d2q9_step2 (0 = auto)
+  int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
+  int chunk_min = 0;        // shortest chunk at the tapered end of a band (0 = auto)
   bool vec4 = true;
   double *av_host = nullptr;  // staging for downloads
 };
@@ -180,22 +184,74 @@ int step_blocks(const lbm_ctx *c, int work_rows) {
   return std::max(1, nb);
 }
 
+void split_rows(int ny, int P, int idx, int *y0, int *rows);
+
 // two-steps-per-launch kernel: usable when one slab holds the whole (periodic) grid
 bool fuse_possible(const lbm_ctx *c) {
   return c->nslabs_global == 1 && c->vec4 && c->p.nx >= 256 && c->p.ny >= 8;
 }
 bool fuse_effective(const lbm_ctx *c) {
   if (!fuse_possible(c)) return false;
-  return c->fuse != 0;
+  if (c->fuse >= 0) return c->fuse != 0;
+  // auto: measured break-even on MI355X is just below 1024x1024 (99 vs 79 GLUPS there, 42 vs 46 at 512x512:
+  // small grids have too few strip x chunk units to fill 2048 wave slots)
+  return (long)c->p.nx * c->p.ny >= 768L * 1024;
 }
-void fuse_geometry(const lbm_ctx *c, Slab &s) {
+// Work decomposition of d2q9_step2: strips x chunks.  A unit's cost is proportional to its rows + 2, and
+// all units of a launch finish at about the same time, so equal chunks leave the chip partly idle during
+// the last round of units (17 % of the launch with 32-row chunks on 8192x8192).  The schedule therefore
+// tapers: every band (the share of one XCD) starts with chunks of `chunk_rows` rows and ends with
+// ever shorter ones (guided self-scheduling), down to `chunk_min`.
+int fuse_geometry(const lbm_ctx *c, Slab &s) {
   const int q4 = c->p.nx / 4;
   s.f_strips = div_up(q4, 62);             // lanes 0 and 63 of every wave are halo lanes
   s.f_lanes = div_up(q4, s.f_strips);
-  s.f_chunk = c->chunk_rows > 0 ? c->chunk_rows : 32;
+  // measured optimum (profiles/r01_fused_sweep.txt): short chunks — the rows concurrently in flight on an
+  // XCD then fit the caches, which absorbs the re-read boundary rows; 6/2 from 4096x4096 up, 8/4 below
+  const bool big = (long)c->p.nx * s.rows >= 8L << 20;
+  s.f_chunk = c->chunk_rows > 0 ? c->chunk_rows : (big ? 6 : 8);
   s.f_chunk = std::max(2, std::min(s.f_chunk, s.rows));
-  s.f_nchunks = div_up(s.rows, s.f_chunk);
-  s.f_units = s.f_strips * s.f_nchunks;
+  const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), s.f_chunk));
+  s.f_nbands = (s.rows >= 8 * 4 * cmin) ? 8 : 1;
+  const int waves_resident = 256 * 8;      // CUs x waves per CU at 2 waves/SIMD
+  const double slots = std::max(1.0, (double)waves_resident / s.f_nbands / s.f_strips);  // concurrent chunks per band
+  std::vector<int> starts;
+  int chunks_per_band = 0;
+  for (int b = 0; b < s.f_nbands; b++) {
+    int y0, rows;
+    split_rows(s.rows, s.f_nbands, b, &y0, &rows);
+    // identical band sizes are required for the unit arithmetic in the kernel: use the largest
+    // band's schedule length and let short bands end with empty chunks
+    std::vector<int> sizes;
+    int rem = rows;
+    while (rem > 0) {
+      int sz = (int)std::ceil(rem / (2.0 * slots));
+      sz = std::max(cmin, std::min(s.f_chunk, sz));
+      sz = std::min(sz, rem);
+      sizes.push_back(sz);
+      rem -= sz;
+    }
+    if (b == 0) chunks_per_band = (int)sizes.size();
+    while ((int)sizes.size() < chunks_per_band) sizes.push_back(0);
+    if ((int)sizes.size() > chunks_per_band) {  // later bands are never longer than band 0 (split_rows)
+      int extra = 0;
+      while ((int)sizes.size() > chunks_per_band) { extra += sizes.back(); sizes.pop_back(); }
+      sizes.back() += extra;
+    }
+    int y = y0;
+    for (int sz : sizes) { starts.push_back(y); y += sz; }
+  }
+  starts.push_back(s.rows);
+  s.f_nchunks = chunks_per_band * s.f_nbands;
+  s.f_units_per_band = chunks_per_band * s.f_strips;
+  s.f_units = s.f_units_per_band * s.f_nbands;
+  s.f_grid = s.f_units;
+  if (set_dev(s)) return LBM_ERR_HIP;
+  if (s.f_chunk_start) HIP_TRY(hipFree(s.f_chunk_start));
+  s.f_chunk_start = nullptr;
+  if (dev_alloc(&s.f_chunk_start, starts.size())) return LBM_ERR_HIP;
+  HIP_TRY(hipMemcpy(s.f_chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
+  return LBM_OK;
 }
 
 bool nt_effective(const lbm_ctx *c) {
@@ -376,15 +432,17 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
         a.ny = s.rows;
         a.strips = s.f_strips;
         a.lanes_out = s.f_lanes;
-        a.chunk_rows = s.f_chunk;
+        a.chunk_start = s.f_chunk_start;
         a.nchunks = s.f_nchunks;
+        a.nbands = s.f_nbands;
+        a.units_per_band = s.f_units_per_band;
         a.accel_row = s.accel_row;
         a.accel_next = (i + 2 < nsteps) ? 1 : 0;
         a.omega = c->p.omega;
         a.aw1 = aw1;
         a.aw2 = aw2;
-        if (nt_effective(c)) hipLaunchKernelGGL((d2q9_step2<true>), dim3(s.f_units), dim3(64), 0, s.s_main, a);
-        else hipLaunchKernelGGL((d2q9_step2<false>), dim3(s.f_units), dim3(64), 0, s.s_main, a);
+        if (nt_effective(c)) hipLaunchKernelGGL((d2q9_step2<true>), dim3(s.f_grid), dim3(64), 0, s.s_main, a);
+        else hipLaunchKernelGGL((d2q9_step2<false>), dim3(s.f_grid), dim3(64), 0, s.s_main, a);
         HIP_TRY(hipGetLastError());
         c->ring_fill += 2;
         i += 2;
@@ -497,6 +555,7 @@ void free_slab(Slab &s) {
   if (s.partials) hipFree(s.partials);
   if (s.av_sum) hipFree(s.av_sum);
   if (s.fin_partials) hipFree(s.fin_partials);
+  if (s.f_chunk_start) hipFree(s.f_chunk_start);
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
@@ -559,7 +618,7 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   }
   s.nb_total = s.nb_main + s.nb_edge;
   if (fuse_possible(c)) {
-    fuse_geometry(c, s);
+    if (int rc = fuse_geometry(c, s)) return rc;
     s.nb_total = std::max(s.nb_total, s.f_units);
   }
   if (dev_alloc(&s.av_sum, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
@@ -604,7 +663,7 @@ int rebuild_geometry(lbm_ctx *c) {
     }
     s.nb_total = s.nb_main + s.nb_edge;
     if (fuse_possible(c)) {
-      fuse_geometry(c, s);
+      if (int rc = fuse_geometry(c, s)) return rc;
       s.nb_total = std::max(s.nb_total, s.f_units);
     }
   }
@@ -924,10 +983,10 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   }
   if (!strcmp(key, "nt_stores")) { c->nt_stores = (int)value; return LBM_OK; }
   if (!strcmp(key, "fuse")) { c->fuse = (int)value; return LBM_OK; }
-  if (!strcmp(key, "chunk_rows")) {
-    if (value < 0) return fail(LBM_ERR_ARG, "chunk_rows must be >= 0");
+  if (!strcmp(key, "chunk_rows") || !strcmp(key, "chunk_min")) {
+    if (value < 0) return fail(LBM_ERR_ARG, "%s must be >= 0", key);
     if (int rc = sync_all(c)) return rc;
-    c->chunk_rows = (int)value;
+    (key[6] == 'r' ? c->chunk_rows : c->chunk_min) = (int)value;
     return rebuild_geometry(c);
   }
   if (!strcmp(key, "use_graph")) { c->use_graph = (int)value; return LBM_OK; }
@@ -942,6 +1001,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
   else if (!strcmp(key, "fuse")) *value = fuse_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_chunk;
+  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_units;
   else if (!strcmp(key, "use_graph")) *value = c->use_graph;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;

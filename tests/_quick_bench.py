@@ -8,18 +8,19 @@ def cavity(nx, ny):
     ob = np.zeros((ny, nx), np.int32); ob[0, :] = ob[-1, :] = 1; ob[:, 0] = ob[:, -1] = 1
     return ob
 
-for (nx, ny, steps) in [(8192, 8192, 100), (1024, 1024, 2000), (256, 256, 4000), (128, 128, 4000)]:
+for (nx, ny, steps) in [(8192, 8192, 100), (4096, 4096, 400), (2048, 2048, 1000), (1024, 1024, 2000)]:
     ob = cavity(nx, ny)
     p = lbm_amd.make_params(nx, ny, 100000, obstacles=ob)
     with lbm_amd.LBM(p, ob) as sim:
-        configs = [("fuse", 0, 0)] + [("fuse", 1, cr) for cr in (8, 16, 32, 64, 128) if cr <= ny]
+        configs = [("fuse", 0, 0, 0)] + [("fuse", 1, cr, cm) for cr in (6, 8, 12, 32) for cm in (2, 4) if cr <= ny and cm <= cr]
         for rnd in range(2):
-            for (_, fuse, cr) in configs:
+            for (_, fuse, cr, cm) in configs:
                 sim.set_option("fuse", fuse)
                 if fuse:
+                    sim.set_option("chunk_min", cm)
                     sim.set_option("chunk_rows", cr)
                 sim.upload(None)
                 sim.run(20)
                 ms = sim.run_timed(steps)
                 mlups = nx * ny * steps / (ms * 1e-3) / 1e6
-                print("%5dx%-5d fuse=%d chunk=%-4d ms/step %.5f  MLUPS %8.0f  GB/s(72B) %6.0f" % (nx, ny, fuse, cr, ms / steps, mlups, mlups * 72e-3), flush=True)
+                print("%5dx%-5d fuse=%d chunk=%-4d min=%d units=%d ms/step %.5f  MLUPS %8.0f  GB/s(72B) %6.0f" % (nx, ny, fuse, cr, cm, sim.get_option("fuse_units"), ms / steps, mlups, mlups * 72e-3), flush=True)
