@@ -37,11 +37,11 @@ write = counters(os.path.join(G, "prof_%s_write" % tag, "write_counter_collectio
 step_fetch = step_write = None
 for (k, c), v in sorted(fetch.items()):
     lines.append("FETCH_SIZE [KiB]  n=%-4d mean=%-14.6g min=%-14.6g max=%-14.6g %s" % (len(v), sum(v) / len(v), min(v), max(v), k[:90]))
-    if "d2q9_step" in k:
-        step_fetch = sum(v) / len(v)
+    if "d2q9_step" in k and (step_fetch is None or sum(v) / len(v) > step_fetch):
+        step_fetch, step_kernel = sum(v) / len(v), k
 for (k, c), v in sorted(write.items()):
     lines.append("WRITE_SIZE [KiB]  n=%-4d mean=%-14.6g min=%-14.6g max=%-14.6g %s" % (len(v), sum(v) / len(v), min(v), max(v), k[:90]))
-    if "d2q9_step" in k:
+    if "d2q9_step" in k and (step_write is None or sum(v) / len(v) > step_write):
         step_write = sum(v) / len(v)
 calib_path = os.path.join(G, "prof_%s_calib" % tag, "calib_counter_collection.csv")
 factor = 2.0
@@ -54,19 +54,21 @@ if os.path.exists(calib_path):
 hbm = (factor * step_fetch + step_write) * 1024
 with open(os.path.join(G, "prof_%s_stats" % tag, "stats_kernel_stats.csv")) as f:
     for r in csv.DictReader(f):
-        if "d2q9_step" in r["Name"]:
+        if r["Name"] == step_kernel:
             avg_ns = float(r["AverageNs"])
             lines.append("kernel-trace: %s calls=%s average=%.1f us" % (r["Name"], r["Calls"], avg_ns / 1e3))
 nx, ny = (int(v) for v in workload.split("x"))
-alg = 72.0 * nx * ny
-lines += ["", "step kernel, %s: FETCH_SIZE %.6g KiB (x2 on gfx950), WRITE_SIZE %.6g KiB" % (workload, step_fetch, step_write),
+fused = "step2" in step_kernel
+alg = 72.0 * nx * ny * (2 if fused else 1)
+lines += ["", "dominant kernel: %s (%d timestep(s) per launch)" % (step_kernel, 2 if fused else 1), "step kernel, %s: FETCH_SIZE %.6g KiB (x2 on gfx950), WRITE_SIZE %.6g KiB" % (workload, step_fetch, step_write),
           "HBM bytes per launch = (2*FETCH + WRITE)*1024 = %.6g  (reads %.6g, writes %.6g)" % (hbm, 2 * step_fetch * 1024, step_write * 1024),
-          "algorithmic bytes per launch = 72 B x %d cells = %.6g ; traffic / algorithmic = %.4f" % (nx * ny, alg, hbm / alg),
+          "algorithmic bytes per launch = 72 B x %d cells x %d step(s) = %.6g ; traffic / algorithmic = %.4f" % (nx * ny, 2 if fused else 1, alg, hbm / alg),
+          "traffic rate = %.1f GB/s" % (hbm / avg_ns),
           "achieved (algorithmic bytes / average kernel time) = %.1f GB/s" % (alg / avg_ns)]
 open(os.path.join(P, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 tj_path = os.path.join(P, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-tj[workload] = {"hbm_bytes_per_launch": round(hbm), "fetch_size_kib": step_fetch, "write_size_kib": step_write,
+tj[workload + ("/fused" if fused else "/single")] = {"hbm_bytes_per_launch": round(hbm), "fetch_size_kib": step_fetch, "write_size_kib": step_write,
                 "source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)" % tag}
 json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
