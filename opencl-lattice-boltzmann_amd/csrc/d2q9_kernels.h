@@ -36,15 +36,14 @@ struct StepArgs {
   const float *src;           // plane 0 of the source grid
   float *dst;                 // plane 0 of the destination grid
   const uint8_t *mask;        // [rows][nx], non-zero = obstacle
-  const float *south_src[3];  // row "y-1" of planes 2,5,6 for y == 0 (periodic wrap row or received halo)
+  const float *south_src[3];  // row "y-1" of planes 2,5,6 for y == 0: the periodic wrap row (kernels.cl:91-93)
   const float *north_src[3];  // row "y+1" of planes 4,7,8 for y == rows-1
-  float *send_south;          // [3][nx]: planes 4,7,8 of the new row 0, or nullptr
-  float *send_north;          // [3][nx]: planes 2,5,6 of the new row rows-1, or nullptr
   float *partials;            // [gridDim.x] per-workgroup sums of |j|/rho
   unsigned long long plane_stride;  // floats between the 9 plane-rows of one grid row (>= nx)
   unsigned long long row_stride;    // floats between consecutive grid rows (>= 9*plane_stride)
-  int nx, rows;               // row length, rows held in this grid
-  int y_begin, y_count, y_step;  // rows y_begin + r*y_step, r < y_count, are processed
+  int nx, rows;               // row length, rows stored in this grid (a slab's halo rows included)
+  int y_begin, y_count;       // rows processed: y_begin + r for r < y_split, y_begin2 + (r - y_split) above
+  int y_split, y_begin2;      //   (two row ranges in one launch: the bottom and the top edge rows of a slab)
   int accel_row;              // local row that gets the next step's accelerate_flow, or -1
   float omega, aw1, aw2;      // relaxation; density*accel/9, density*accel/36 (kernels.cl:14-15)
 };
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
   for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
     const unsigned r = t / tpr;
     const int x0 = (int)(t - r * tpr) * VEC;
-    const int y = a.y_begin + (int)r * a.y_step;
+    const int y = ((int)r < a.y_split) ? a.y_begin + (int)r : a.y_begin2 + ((int)r - a.y_split);
     const size_t row = (size_t)y * rs;
     // neighbour columns with periodic wrap (kernels.cl:99-102)
     const int xw = (x0 == 0) ? a.nx - 1 : x0 - 1;
@@ -335,25 +334,9 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
     if constexpr (VEC == 4) {
 #pragma unroll
       for (int k = 0; k < 9; k++) store4<NT>(d + k * ps, o[k][0], o[k][1], o[k][2], o[k][3]);
-      if (a.send_south != nullptr && at_south) {
-        store4<false>(a.send_south + 0 * a.nx + x0, o[4][0], o[4][1], o[4][2], o[4][3]);
-        store4<false>(a.send_south + 1 * a.nx + x0, o[7][0], o[7][1], o[7][2], o[7][3]);
-        store4<false>(a.send_south + 2 * a.nx + x0, o[8][0], o[8][1], o[8][2], o[8][3]);
-      }
-      if (a.send_north != nullptr && at_north) {
-        store4<false>(a.send_north + 0 * a.nx + x0, o[2][0], o[2][1], o[2][2], o[2][3]);
-        store4<false>(a.send_north + 1 * a.nx + x0, o[5][0], o[5][1], o[5][2], o[5][3]);
-        store4<false>(a.send_north + 2 * a.nx + x0, o[6][0], o[6][1], o[6][2], o[6][3]);
-      }
     } else {
 #pragma unroll
       for (int k = 0; k < 9; k++) d[k * ps] = o[k][0];
-      if (a.send_south != nullptr && at_south) {
-        a.send_south[0 * a.nx + x0] = o[4][0]; a.send_south[1 * a.nx + x0] = o[7][0]; a.send_south[2 * a.nx + x0] = o[8][0];
-      }
-      if (a.send_north != nullptr && at_north) {
-        a.send_north[0 * a.nx + x0] = o[2][0]; a.send_north[1 * a.nx + x0] = o[5][0]; a.send_north[2 * a.nx + x0] = o[6][0];
-      }
     }
   }
   block_store_partial(tot_u, a.partials);
@@ -382,6 +365,7 @@ struct Step2Args {
   const int *chunk_start;      // [nchunks+1] first row of every chunk (chunks get shorter towards the end of a band)
   int nchunks;                 // units = strips * nchunks
   int nbands, units_per_band;  // workgroup b works on unit (b % nbands)*units_per_band + b / nbands
+  int skip_chunk;              // chunk index whose units do nothing (-1: none); slab mode's edge launch skips the interior
   int accel_row;               // row ny-2
   int accel_next;              // apply the following step's accelerate_flow to the output row ny-2
   float omega, aw1, aw2;
@@ -454,7 +438,7 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
   const int ys = a.chunk_start[chunk];
   const int ye = a.chunk_start[chunk + 1];
-  if (ys >= ye) {  // padding chunk of a short band
+  if (ys >= ye || chunk == a.skip_chunk) {  // padding chunk of a short band / not this launch's business
     if (lane == 0) a.partials1[unit] = a.partials2[unit] = 0.f;
     return;
   }
@@ -569,20 +553,6 @@ __global__ void accelerate_row(float *cells, unsigned long long plane_stride, un
     cells[6 * plane_stride + c] = f6 - aw2;
     cells[7 * plane_stride + c] = f7 - aw2;
   }
-}
-
-// packs the boundary rows of a grid into the halo send buffers (start of a run, slab mode)
-__global__ void pack_halo_rows(const float *cells, unsigned long long plane_stride, unsigned long long row_stride, int nx,
-                               int rows, float *send_south, float *send_north) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= nx) return;
-  const size_t top = (size_t)(rows - 1) * row_stride + x;
-  send_south[0 * nx + x] = cells[4 * plane_stride + x];
-  send_south[1 * nx + x] = cells[7 * plane_stride + x];
-  send_south[2 * nx + x] = cells[8 * plane_stride + x];
-  send_north[0 * nx + x] = cells[2 * plane_stride + top];
-  send_north[1 * nx + x] = cells[5 * plane_stride + top];
-  send_north[2 * nx + x] = cells[6 * plane_stride + top];
 }
 
 // ---- initial state on the device (values of d2q9-bgk.c:529-550) ---------------------------------

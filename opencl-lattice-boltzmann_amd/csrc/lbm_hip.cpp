@@ -7,11 +7,13 @@
 //
 // Structure: a context owns one or more row SLABS.  A slab is a contiguous range of grid rows on
 // one GPU with its own pair of grids, mask, streams and reduction buffers.  With one slab the y
-// wrap-around is resolved inside the kernel (the "halo" rows are the slab's own first/last rows).
-// With several slabs each slab's two edge rows are computed first on an edge stream, their three
-// outgoing distributions are packed by the kernel into send buffers and exchanged with the ring
-// neighbours (RCCL send/recv over xGMI, or device-to-device copies when slabs share a process and
-// RCCL cannot be used), while the interior rows are computed on the main stream.
+// wrap-around is resolved inside the kernels.  With several slabs every slab stores two HALO rows
+// below and above its own rows inside the same row-interleaved arrays; after each launch set (two
+// timesteps with the fused kernel, one otherwise) a slab sends its two bottom and two top rows —
+// each pair one contiguous block — to its ring neighbours' halo rows (RCCL send/recv over xGMI, or
+// device-to-device copies when slabs share a process and RCCL cannot be used).  The chunks next to
+// the slab edges are computed first on an edge stream, so the exchange overlaps the interior work
+// on the main stream; events join the two streams once per launch set.
 #include "../../include/lbm.h"
 #include "d2q9_kernels.h"
 
@@ -100,33 +102,42 @@ int load_rccl() {
 constexpr int kRingMax = 256;  // most steps of per-workgroup partial sums buffered between reductions
 enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2 };
 
+// unit schedule of one d2q9_step2 launch (see fuse_schedule)
+struct FuseGeom {
+  int *chunk_start = nullptr;  // device array [nchunks+1]
+  int nchunks = 0, nbands = 1, units_per_band = 0, units = 0;
+};
+
 struct Slab {
   int dev = 0;
   int index = 0;          // position in the global ring of slabs
-  int y0 = 0, rows = 0;   // global first row, rows held
-  int accel_row = -1;     // local index of global row ny-2, or -1
+  int y0 = 0, rows = 0;   // global first row, rows owned
+  int row0 = 0;           // halo rows stored below (and above) the owned rows: 0 (one slab) or 2
+  int ext_rows = 0;       // rows stored = rows + 2*row0
+  int accel_own = -1;     // stored-row index of global row ny-2 if this slab owns it, else -1
+  int accel_ext = -1;     // same, also when the row is one of the halo-adjacent rows row0-1 / row0+rows
   size_t plane_stride = 0;  // floats between the 9 plane-rows of a grid row (padded row length)
   size_t row_stride = 0;    // floats between grid rows = 9*plane_stride (+ pad)
-  float *cells[2] = {nullptr, nullptr};
-  uint8_t *mask = nullptr;
-  // halo buffers, 3*nx floats each: [parity][0 = south side, 1 = north side]
-  float *halo_send[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  float *halo_recv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  float *cells[2] = {nullptr, nullptr};  // [ext_rows][9][plane_stride]
+  uint8_t *mask = nullptr;               // [ext_rows][nx]
   float *partials = nullptr;  // [ring][nb_total]
-  int nb_main = 0, nb_edge = 0, nb_total = 0;  // workgroups of the interior / edge launch; slot stride of the ring
-  int f_strips = 0, f_lanes = 0, f_chunk = 0, f_nchunks = 0, f_units = 0;  // geometry of d2q9_step2
-  int f_nbands = 1, f_units_per_band = 0, f_grid = 0;
-  int *f_chunk_start = nullptr;  // device copy of the chunk schedule
+  int nb_main = 0, nb_edge = 0;  // workgroups of the single-step interior / edge launch
+  int nb_total = 0;              // slot stride of the ring
+  int strips = 0, lanes_out = 0;  // x decomposition of d2q9_step2
+  FuseGeom f_main, f_edge;        // whole slab (one slab) or interior chunks; the two edge chunks
+  int edge_rows = 0;              // rows per edge chunk in slab mode
   double *av_sum = nullptr;   // [capacity] per-step sum of |j|/rho over this slab's fluid cells
   hipStream_t s_main = nullptr, s_edge = nullptr;
-  hipEvent_t ev_main[2] = {nullptr, nullptr};   // interior kernel of a step done
-  hipEvent_t ev_edgek[2] = {nullptr, nullptr};  // edge kernel of a step done (send buffers packed)
-  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;     // timing of lbm_run_timed
-  hipEvent_t ev_aux = nullptr;                     // cross-stream ordering inside a run
+  hipEvent_t ev_main[2] = {nullptr, nullptr};   // interior launch of a launch set done
+  hipEvent_t ev_edgek[2] = {nullptr, nullptr};  // edge launch of a launch set done (edge rows final)
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // timing of lbm_run_timed
+  hipEvent_t ev_aux = nullptr;                  // cross-stream ordering inside a run
   ncclComm_t comm = nullptr;
   // output-stage scratch
   float *fin_partials = nullptr;
   int fin_blocks = 0;
+  float *own(int buf) const { return cells[buf] + (size_t)row0 * row_stride; }
+  const uint8_t *mask_own(int nx) const { return mask + (size_t)row0 * nx; }
 };
 
 }  // namespace
@@ -172,92 +183,140 @@ int dev_alloc(T **p, size_t count) {
   return LBM_OK;
 }
 
-// launch geometry of the step kernel for `work_rows` rows of a slab
+// launch geometry of the single-step kernel for `work_rows` rows
 int step_blocks(const lbm_ctx *c, int work_rows) {
   const int vec = c->vec4 ? 4 : 1;
   const long threads = (long)(c->p.nx / vec) * work_rows;
   // default: one 256-thread tile per workgroup, no grid-stride.  Measured on 8192x8192: 65536 one-tile
   // workgroups 0.795 ms/step vs 0.85 ms with 2048 persistent ones (the dispatcher walks the grid in
-  // address order and keeps every CU's queue full; profiles/r01_tune.txt)
+  // address order and keeps every CU's queue full; profiles/r01_tune_layout_grid.txt)
   int nb = div_up(threads, kBlock);
   if (c->grid_blocks > 0) nb = std::min(nb, c->grid_blocks);
   return std::max(1, nb);
 }
 
-void split_rows(int ny, int P, int idx, int *y0, int *rows);
+void split_rows(int ny, int P, int idx, int *y0, int *rows) {
+  const int base = ny / P, rem = ny % P;
+  *y0 = idx * base + std::min(idx, rem);
+  *rows = base + (idx < rem ? 1 : 0);
+}
 
-// two-steps-per-launch kernel: usable when one slab holds the whole (periodic) grid
+// two-steps-per-launch kernel: float4 rows of at least one wave, a few rows per slab
 bool fuse_possible(const lbm_ctx *c) {
-  return c->nslabs_global == 1 && c->vec4 && c->p.nx >= 256 && c->p.ny >= 8;
+  if (!c->vec4 || c->p.nx < 256) return false;
+  for (const Slab &s : c->slabs)
+    if (s.rows < 8) return false;
+  return true;
 }
 bool fuse_effective(const lbm_ctx *c) {
   if (!fuse_possible(c)) return false;
   if (c->fuse >= 0) return c->fuse != 0;
   // auto: measured break-even on MI355X is just below 1024x1024 (99 vs 79 GLUPS there, 42 vs 46 at 512x512:
   // small grids have too few strip x chunk units to fill 2048 wave slots)
-  return (long)c->p.nx * c->p.ny >= 768L * 1024;
+  return (long)c->p.nx * c->slabs[0].rows >= 768L * 1024;
 }
-// Work decomposition of d2q9_step2: strips x chunks.  A unit's cost is proportional to its rows + 2, and
-// all units of a launch finish at about the same time, so equal chunks leave the chip partly idle during
-// the last round of units (17 % of the launch with 32-row chunks on 8192x8192).  The schedule therefore
-// tapers: every band (the share of one XCD) starts with chunks of `chunk_rows` rows and ends with
-// ever shorter ones (guided self-scheduling), down to `chunk_min`.
-int fuse_geometry(const lbm_ctx *c, Slab &s) {
-  const int q4 = c->p.nx / 4;
-  s.f_strips = div_up(q4, 62);             // lanes 0 and 63 of every wave are halo lanes
-  s.f_lanes = div_up(q4, s.f_strips);
-  // measured optimum (profiles/r01_fused_sweep.txt): short chunks — the rows concurrently in flight on an
-  // XCD then fit the caches, which absorbs the re-read boundary rows; 6/2 from 4096x4096 up, 8/4 below
-  const bool big = (long)c->p.nx * s.rows >= 8L << 20;
-  s.f_chunk = c->chunk_rows > 0 ? c->chunk_rows : (big ? 6 : 8);
-  s.f_chunk = std::max(2, std::min(s.f_chunk, s.rows));
-  const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), s.f_chunk));
-  s.f_nbands = (s.rows >= 8 * 4 * cmin) ? 8 : 1;
-  const int waves_resident = 256 * 8;      // CUs x waves per CU at 2 waves/SIMD
-  const double slots = std::max(1.0, (double)waves_resident / s.f_nbands / s.f_strips);  // concurrent chunks per band
+
+// Work decomposition of d2q9_step2 over stored rows [r0, r1): strips x chunks.  A unit's cost is
+// proportional to its rows + 2 and all units of a launch finish at about the same time, so equal chunks
+// leave the chip partly idle during the last round of units (17 % of the launch with 32-row chunks on
+// 8192x8192).  The schedule therefore tapers: every band (the share of one XCD) starts with chunks of
+// `cmax` rows and ends with ever shorter ones (guided self-scheduling), down to `cmin`.
+int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g) {
+  const int rows = r1 - r0;
+  g.nbands = (allow_bands && rows >= 8 * 4 * cmin) ? 8 : 1;
+  const int waves_resident = 256 * 8;  // CUs x waves per CU at 2 waves/SIMD
+  const double slots = std::max(1.0, (double)waves_resident / g.nbands / s.strips);  // concurrent chunks per band
   std::vector<int> starts;
   int chunks_per_band = 0;
-  for (int b = 0; b < s.f_nbands; b++) {
-    int y0, rows;
-    split_rows(s.rows, s.f_nbands, b, &y0, &rows);
-    // identical band sizes are required for the unit arithmetic in the kernel: use the largest
-    // band's schedule length and let short bands end with empty chunks
+  for (int b = 0; b < g.nbands; b++) {
+    int y0, n;
+    split_rows(rows, g.nbands, b, &y0, &n);
     std::vector<int> sizes;
-    int rem = rows;
+    int rem = n;
     while (rem > 0) {
       int sz = (int)std::ceil(rem / (2.0 * slots));
-      sz = std::max(cmin, std::min(s.f_chunk, sz));
-      sz = std::min(sz, rem);
+      sz = std::min(std::max(cmin, std::min(cmax, sz)), rem);
       sizes.push_back(sz);
       rem -= sz;
     }
+    // all bands need the same number of chunks (unit arithmetic in the kernel): band 0 is never
+    // shorter than the others (split_rows); pad with empty chunks / merge surplus into the last one
     if (b == 0) chunks_per_band = (int)sizes.size();
     while ((int)sizes.size() < chunks_per_band) sizes.push_back(0);
-    if ((int)sizes.size() > chunks_per_band) {  // later bands are never longer than band 0 (split_rows)
-      int extra = 0;
-      while ((int)sizes.size() > chunks_per_band) { extra += sizes.back(); sizes.pop_back(); }
-      sizes.back() += extra;
-    }
-    int y = y0;
+    int extra = 0;
+    while ((int)sizes.size() > chunks_per_band) { extra += sizes.back(); sizes.pop_back(); }
+    if (extra) sizes.back() += extra;
+    int y = r0 + y0;
     for (int sz : sizes) { starts.push_back(y); y += sz; }
   }
-  starts.push_back(s.rows);
-  s.f_nchunks = chunks_per_band * s.f_nbands;
-  s.f_units_per_band = chunks_per_band * s.f_strips;
-  s.f_units = s.f_units_per_band * s.f_nbands;
-  s.f_grid = s.f_units;
+  starts.push_back(r1);
+  g.nchunks = chunks_per_band * g.nbands;
+  g.units_per_band = chunks_per_band * s.strips;
+  g.units = g.units_per_band * g.nbands;
   if (set_dev(s)) return LBM_ERR_HIP;
-  if (s.f_chunk_start) HIP_TRY(hipFree(s.f_chunk_start));
-  s.f_chunk_start = nullptr;
-  if (dev_alloc(&s.f_chunk_start, starts.size())) return LBM_ERR_HIP;
-  HIP_TRY(hipMemcpy(s.f_chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (g.chunk_start) HIP_TRY(hipFree(g.chunk_start));
+  g.chunk_start = nullptr;
+  if (dev_alloc(&g.chunk_start, starts.size())) return LBM_ERR_HIP;
+  HIP_TRY(hipMemcpy(g.chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
+  return LBM_OK;
+}
+
+// All launch geometry of a slab (single-step workgroup counts, fused schedules, ring slot stride).
+int slab_geometry(const lbm_ctx *c, Slab &s) {
+  const bool multi = c->nslabs_global > 1;
+  if (multi) {
+    // single-step kernel in slab mode: 2 bottom + 2 top rows first (what the neighbours receive), then the rest
+    s.nb_edge = step_blocks(c, 4);
+    s.nb_main = step_blocks(c, std::max(1, s.rows - 4));
+  } else {
+    s.nb_main = step_blocks(c, s.rows);
+    s.nb_edge = 0;
+  }
+  s.nb_total = s.nb_main + s.nb_edge;
+  if (fuse_possible(c)) {
+    const int q4 = c->p.nx / 4;
+    s.strips = div_up(q4, 62);  // lanes 0 and 63 of every wave are halo lanes
+    s.lanes_out = div_up(q4, s.strips);
+    // measured optimum (profiles/r01_fused_sweep.txt): short chunks — the rows concurrently in flight on an
+    // XCD then fit the caches, which absorbs the re-read boundary rows; 6/2 from 4096x4096 up, 8/4 below
+    const bool big = (long)c->p.nx * s.rows >= 8L << 20;
+    int cmax = c->chunk_rows > 0 ? c->chunk_rows : (big ? 6 : 8);
+    cmax = std::max(2, std::min(cmax, s.rows));
+    const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), cmax));
+    if (multi) {
+      // the two edge chunks hold the rows the neighbours need (2 each); the interior is everything else
+      s.edge_rows = std::min(std::max(2, cmax), s.rows / 2);
+      FuseGeom &e = s.f_edge;
+      // edge schedule: chunk table {bottom edge, interior, top edge}; the launch skips chunk 1
+      std::vector<int> tab = {s.row0, s.row0 + s.edge_rows, s.row0 + s.rows - s.edge_rows, s.row0 + s.rows};
+      if (set_dev(s)) return LBM_ERR_HIP;
+      if (e.chunk_start) HIP_TRY(hipFree(e.chunk_start));
+      e.chunk_start = nullptr;
+      if (dev_alloc(&e.chunk_start, tab.size())) return LBM_ERR_HIP;
+      HIP_TRY(hipMemcpy(e.chunk_start, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+      e.nchunks = 3;  // chunk 1 = [row0+edge, row0+rows-edge) is skipped by the kernel (edge_only)
+      e.nbands = 1;
+      e.units_per_band = 3 * s.strips;
+      e.units = e.units_per_band;
+      const int i0 = s.row0 + s.edge_rows, i1 = s.row0 + s.rows - s.edge_rows;
+      if (i1 > i0) {
+        if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main)) return rc;
+      } else {
+        s.f_main.units = 0;
+      }
+      s.nb_total = std::max(s.nb_total, s.f_main.units + e.units);
+    } else {
+      if (int rc = fuse_schedule(s, 0, s.rows, cmax, cmin, true, s.f_main)) return rc;
+      s.nb_total = std::max(s.nb_total, s.f_main.units);
+    }
+  }
   return LBM_OK;
 }
 
 bool nt_effective(const lbm_ctx *c) {
   if (c->nt_stores >= 0) return c->nt_stores != 0;
   // both grids of a slab fit the 256 MiB Infinity Cache -> keep the written lines cacheable
-  const size_t grid_bytes = c->slabs[0].row_stride * c->slabs[0].rows * sizeof(float);
+  const size_t grid_bytes = c->slabs[0].row_stride * c->slabs[0].ext_rows * sizeof(float);
   return 2 * grid_bytes > ((size_t)192 << 20);
 }
 
@@ -292,6 +351,7 @@ void launch_step(const lbm_ctx *c, const StepArgs &a, int nblocks, hipStream_t s
   }
 }
 
+// single-step kernel arguments common to all launches of a slab; rows are STORED-row indices
 StepArgs base_args(const lbm_ctx *c, const Slab &s, int src, bool apply_accel) {
   StepArgs a{};
   a.src = s.cells[src];
@@ -300,40 +360,78 @@ StepArgs base_args(const lbm_ctx *c, const Slab &s, int src, bool apply_accel) {
   a.plane_stride = s.plane_stride;
   a.row_stride = s.row_stride;
   a.nx = c->p.nx;
-  a.rows = s.rows;
-  a.accel_row = apply_accel ? s.accel_row : -1;
+  a.rows = s.ext_rows;
+  a.accel_row = apply_accel ? s.accel_own : -1;
+  a.omega = c->p.omega;
+  a.aw1 = c->p.density * c->p.accel / 9.0f;
+  a.aw2 = c->p.density * c->p.accel / 36.0f;
+  for (int k = 0; k < 3; k++) {
+    static const int sp[3] = {2, 5, 6}, np[3] = {4, 7, 8};
+    // only dereferenced for stored row 0 / ext_rows-1, i.e. with one slab: the y wrap (kernels.cl:91-93)
+    a.south_src[k] = s.cells[src] + sp[k] * s.plane_stride + (size_t)(s.ext_rows - 1) * s.row_stride;
+    a.north_src[k] = s.cells[src] + np[k] * s.plane_stride;
+  }
+  return a;
+}
+
+Step2Args base_args2(const lbm_ctx *c, const Slab &s, int src, bool accel_next, const FuseGeom &g) {
+  Step2Args a{};
+  a.src = s.cells[src];
+  a.dst = s.cells[src ^ 1];
+  a.mask = s.mask;
+  a.plane_stride = s.plane_stride;
+  a.row_stride = s.row_stride;
+  a.nx = c->p.nx;
+  a.ny = s.ext_rows;  // rows wrap only with one slab; with halos the chunks never reach row 0 / ext_rows-1
+  a.strips = s.strips;
+  a.lanes_out = s.lanes_out;
+  a.chunk_start = g.chunk_start;
+  a.nchunks = g.nchunks;
+  a.nbands = g.nbands;
+  a.units_per_band = g.units_per_band;
+  a.skip_chunk = -1;
+  a.accel_row = s.accel_ext;
+  a.accel_next = accel_next ? 1 : 0;
   a.omega = c->p.omega;
   a.aw1 = c->p.density * c->p.accel / 9.0f;
   a.aw2 = c->p.density * c->p.accel / 36.0f;
   return a;
 }
 
-// Move the packed edge rows of step parity q to the ring neighbours' receive buffers.
-int exchange_halos(lbm_ctx *c, int q) {
-  const size_t count = (size_t)3 * c->p.nx;
+void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t st) {
+  if (nt_effective(c)) hipLaunchKernelGGL((d2q9_step2<true>), dim3(units), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((d2q9_step2<false>), dim3(units), dim3(64), 0, st, a);
+}
+
+// Slab mode: move the two bottom and the two top owned rows of grid `buf` into the ring neighbours'
+// halo rows of their grid `buf`.  Each pair of rows is one contiguous block of 2*row_stride floats.
+int exchange_halos(lbm_ctx *c, int buf, int evq) {
   const int P = c->nslabs_global;
   if (c->transport_eff == TRANSPORT_RCCL) {
     NCCL_TRY(g_rccl.GroupStart());
     for (Slab &s : c->slabs) {
+      const size_t count = 2 * s.row_stride;
       const int north = (s.index + 1) % P, south = (s.index + P - 1) % P;
-      // my top row's planes 2,5,6 feed the north neighbour's south halo; my bottom row's 4,7,8 feed
-      // the south neighbour's north halo
-      NCCL_TRY(g_rccl.Send(s.halo_send[q][1], count, ncclFloat, north, s.comm, s.s_edge));
-      NCCL_TRY(g_rccl.Send(s.halo_send[q][0], count, ncclFloat, south, s.comm, s.s_edge));
-      NCCL_TRY(g_rccl.Recv(s.halo_recv[q][0], count, ncclFloat, south, s.comm, s.s_edge));
-      NCCL_TRY(g_rccl.Recv(s.halo_recv[q][1], count, ncclFloat, north, s.comm, s.s_edge));
+      float *g = s.cells[buf];
+      NCCL_TRY(g_rccl.Send(g + (size_t)(s.row0 + s.rows - 2) * s.row_stride, count, ncclFloat, north, s.comm, s.s_edge));
+      NCCL_TRY(g_rccl.Send(g + (size_t)s.row0 * s.row_stride, count, ncclFloat, south, s.comm, s.s_edge));
+      NCCL_TRY(g_rccl.Recv(g, count, ncclFloat, south, s.comm, s.s_edge));
+      NCCL_TRY(g_rccl.Recv(g + (size_t)(s.row0 + s.rows) * s.row_stride, count, ncclFloat, north, s.comm, s.s_edge));
     }
     NCCL_TRY(g_rccl.GroupEnd());
   } else {
-    // single process: each slab pulls from its neighbours once their edge kernels are done
+    // one process: each slab pulls from its neighbours once their edge launches are done
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
+      const size_t bytes = 2 * s.row_stride * sizeof(float);
       Slab &north = c->slabs[(s.index + 1) % P];
       Slab &south = c->slabs[(s.index + P - 1) % P];
-      HIP_TRY(hipStreamWaitEvent(s.s_edge, south.ev_edgek[q], 0));
-      HIP_TRY(hipStreamWaitEvent(s.s_edge, north.ev_edgek[q], 0));
-      HIP_TRY(hipMemcpyAsync(s.halo_recv[q][0], south.halo_send[q][1], count * sizeof(float), hipMemcpyDeviceToDevice, s.s_edge));
-      HIP_TRY(hipMemcpyAsync(s.halo_recv[q][1], north.halo_send[q][0], count * sizeof(float), hipMemcpyDeviceToDevice, s.s_edge));
+      HIP_TRY(hipStreamWaitEvent(s.s_edge, south.ev_edgek[evq], 0));
+      HIP_TRY(hipStreamWaitEvent(s.s_edge, north.ev_edgek[evq], 0));
+      HIP_TRY(hipMemcpyAsync(s.cells[buf], south.cells[buf] + (size_t)(south.row0 + south.rows - 2) * south.row_stride, bytes,
+                             hipMemcpyDeviceToDevice, s.s_edge));
+      HIP_TRY(hipMemcpyAsync(s.cells[buf] + (size_t)(s.row0 + s.rows) * s.row_stride,
+                             north.cells[buf] + (size_t)north.row0 * north.row_stride, bytes, hipMemcpyDeviceToDevice, s.s_edge));
     }
   }
   return LBM_OK;
@@ -347,33 +445,30 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
   if (timed && ms) *ms = 0.0;
   if (nsteps == 0) return LBM_OK;
   const bool multi = c->nslabs_global > 1;
+  const bool fuse = fuse_effective(c);
   const float aw1 = c->p.density * c->p.accel / 9.0f, aw2 = c->p.density * c->p.accel / 36.0f;
   const int nx = c->p.nx;
 
   // prologue: accelerate_flow of the first step on the current grid (kernels.cl:9-53); later
-  // steps get theirs fused into the previous step's write of row ny-2
+  // steps get theirs fused into the previous launch's write of row ny-2
   for (Slab &s : c->slabs) {
     if (set_dev(s)) return LBM_ERR_HIP;
     if (multi) HIP_TRY(hipStreamSynchronize(s.s_edge));
-    if (s.accel_row >= 0) {
+    if (s.accel_own >= 0) {
       hipLaunchKernelGGL(accelerate_row, dim3(div_up(nx, 128)), dim3(128), 0, s.s_main, s.cells[c->cur], s.plane_stride,
-                         s.row_stride, s.mask, nx, s.accel_row, aw1, aw2);
+                         s.row_stride, s.mask, nx, s.accel_own, aw1, aw2);
       HIP_TRY(hipGetLastError());
     }
   }
   if (multi) {
-    // halos of the initial state: pack the edge rows of the current grid and exchange them as if
-    // they were the result of step "-1" (parity 1)
+    // halos of the initial state ("launch set -1", event parity 1)
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
-      hipLaunchKernelGGL(pack_halo_rows, dim3(div_up(nx, 128)), dim3(128), 0, s.s_main, s.cells[c->cur], s.plane_stride,
-                         s.row_stride, nx, s.rows, s.halo_send[1][0], s.halo_send[1][1]);
-      HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(s.ev_main[1], s.s_main));
       HIP_TRY(hipEventRecord(s.ev_edgek[1], s.s_main));
       HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[1], 0));
     }
-    if (int rc = exchange_halos(c, 1)) return rc;
+    if (int rc = exchange_halos(c, c->cur, 1)) return rc;
   }
   if (timed)
     for (Slab &s : c->slabs) {
@@ -387,19 +482,21 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     }
 
   int batch_first = c->steps_done;
-  int batch_nb = 0;  // partial sums per slot in the current batch (differs between launch kinds)
+  int batch_kind = 0;  // 1 = single-step launches, 2 = two-step launches in the current batch of the ring
+  int last_q = 1;
   // second reduction stage over the buffered steps of all slabs (kernels.cl:234-290 counterpart)
-  auto flush = [&](int lastq) -> int {
+  auto flush = [&]() -> int {
     const int fill = c->ring_fill;
     if (fill == 0) return LBM_OK;
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
-      if (multi) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[lastq], 0));
-      hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total,
-                         multi ? s.nb_total : batch_nb, s.av_sum + batch_first);
+      if (multi) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[last_q], 0));
+      const int used = batch_kind == 2 ? s.f_main.units + (multi ? s.f_edge.units : 0) : s.nb_main + s.nb_edge;
+      hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
+                         s.av_sum + batch_first);
       HIP_TRY(hipGetLastError());
       if (multi) {
-        // the next batch's edge kernels overwrite ring slots: order them after this reduction
+        // the next batch's edge launches overwrite ring slots: order them after this reduction
         HIP_TRY(hipEventRecord(s.ev_aux, s.s_main));
         HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_aux, 0));
       }
@@ -409,108 +506,81 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     return LBM_OK;
   };
 
-  if (!multi) {
-    Slab &s = c->slabs[0];
-    const bool fuse = fuse_effective(c);
-    int i = 0;
-    while (i < nsteps) {
-      const int src = c->cur;
-      if (fuse && nsteps - i >= 2) {
-        // steps i and i+1 in one pass over the grid
-        if (batch_nb != s.f_units || c->ring_fill + 2 > c->ring)
-          if (int rc = flush(0)) return rc;
-        batch_nb = s.f_units;
-        Step2Args a{};
-        a.src = s.cells[src];
-        a.dst = s.cells[src ^ 1];
-        a.mask = s.mask;
-        a.partials1 = s.partials + (size_t)c->ring_fill * s.nb_total;
-        a.partials2 = s.partials + (size_t)(c->ring_fill + 1) * s.nb_total;
-        a.plane_stride = s.plane_stride;
-        a.row_stride = s.row_stride;
-        a.nx = nx;
-        a.ny = s.rows;
-        a.strips = s.f_strips;
-        a.lanes_out = s.f_lanes;
-        a.chunk_start = s.f_chunk_start;
-        a.nchunks = s.f_nchunks;
-        a.nbands = s.f_nbands;
-        a.units_per_band = s.f_units_per_band;
-        a.accel_row = s.accel_row;
-        a.accel_next = (i + 2 < nsteps) ? 1 : 0;
-        a.omega = c->p.omega;
-        a.aw1 = aw1;
-        a.aw2 = aw2;
-        if (nt_effective(c)) hipLaunchKernelGGL((d2q9_step2<true>), dim3(s.f_grid), dim3(64), 0, s.s_main, a);
-        else hipLaunchKernelGGL((d2q9_step2<false>), dim3(s.f_grid), dim3(64), 0, s.s_main, a);
-        HIP_TRY(hipGetLastError());
-        c->ring_fill += 2;
-        i += 2;
-      } else {
-        if (batch_nb != s.nb_main || c->ring_fill + 1 > c->ring)
-          if (int rc = flush(0)) return rc;
-        batch_nb = s.nb_main;
-        const bool last = (i == nsteps - 1);
-        StepArgs a = base_args(c, s, src, !last);
-        for (int k = 0; k < 3; k++) {
-          static const int sp[3] = {2, 5, 6}, np[3] = {4, 7, 8};
-          a.south_src[k] = s.cells[src] + sp[k] * s.plane_stride + (size_t)(s.rows - 1) * s.row_stride;  // y wrap (kernels.cl:91-93)
-          a.north_src[k] = s.cells[src] + np[k] * s.plane_stride;
+  int i = 0, set = 0;
+  while (i < nsteps) {
+    const int src = c->cur;
+    const int adv = (fuse && nsteps - i >= 2) ? 2 : 1;  // timesteps advanced by this launch set
+    const bool last = (i + adv == nsteps);
+    const int q = set & 1, qp = q ^ 1;  // event parity of this launch set / of the previous one
+    if (batch_kind != adv || c->ring_fill + adv > c->ring)
+      if (int rc = flush()) return rc;
+    batch_kind = adv;
+    for (Slab &s : c->slabs) {
+      if (multi && set_dev(s)) return LBM_ERR_HIP;
+      float *slot1 = s.partials + (size_t)c->ring_fill * s.nb_total;
+      float *slot2 = slot1 + s.nb_total;
+      if (!multi) {
+        if (adv == 2) {
+          Step2Args a = base_args2(c, s, src, !last, s.f_main);
+          a.partials1 = slot1;
+          a.partials2 = slot2;
+          launch_step2(c, a, s.f_main.units, s.s_main);
+        } else {
+          StepArgs a = base_args(c, s, src, !last);
+          a.y_begin = 0; a.y_count = s.rows; a.y_split = s.rows; a.y_begin2 = 0;
+          a.partials = slot1;
+          launch_step(c, a, s.nb_main, s.s_main);
         }
-        a.y_begin = 0; a.y_count = s.rows; a.y_step = 1;
-        a.partials = s.partials + (size_t)c->ring_fill * s.nb_total;
-        launch_step(c, a, s.nb_main, s.s_main);
         HIP_TRY(hipGetLastError());
-        c->ring_fill += 1;
-        i += 1;
+        continue;
       }
-      c->cur ^= 1;
-    }
-    if (int rc = flush(0)) return rc;
-  } else {
-    for (int i = 0; i < nsteps; i++) {
-      const bool last = (i == nsteps - 1);
-      const int q = i & 1, qp = q ^ 1;  // parity of this step / of the previous one (initial state = 1)
-      const int src = c->cur;
-      for (Slab &s : c->slabs) {
-        if (set_dev(s)) return LBM_ERR_HIP;
-        float *part = s.partials + (size_t)c->ring_fill * s.nb_total;
-        // edge rows 0 and rows-1: need the previous step's halos (edge stream order) and interior
-        HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
-        StepArgs e = base_args(c, s, src, !last);
-        for (int k = 0; k < 3; k++) {
-          e.south_src[k] = s.halo_recv[qp][0] + (size_t)k * nx;
-          e.north_src[k] = s.halo_recv[qp][1] + (size_t)k * nx;
+      // ---- slab mode: edge rows first (they feed the neighbours), interior meanwhile ----
+      // edge launch: needs the previous set's halos (edge stream order) and interior (event)
+      HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
+      // interior launch: needs the previous set's edge rows
+      HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
+      if (adv == 2) {
+        Step2Args e = base_args2(c, s, src, !last, s.f_edge);
+        e.skip_chunk = 1;  // chunk table {bottom edge, (interior), top edge}
+        e.partials1 = slot1 + s.f_main.units;
+        e.partials2 = slot2 + s.f_main.units;
+        launch_step2(c, e, s.f_edge.units, s.s_edge);
+        HIP_TRY(hipGetLastError());
+        if (s.f_main.units > 0) {
+          Step2Args m = base_args2(c, s, src, !last, s.f_main);
+          m.partials1 = slot1;
+          m.partials2 = slot2;
+          launch_step2(c, m, s.f_main.units, s.s_main);
+          HIP_TRY(hipGetLastError());
         }
-        e.send_south = s.halo_send[q][0];
-        e.send_north = s.halo_send[q][1];
-        e.y_begin = 0; e.y_count = 2; e.y_step = s.rows - 1;
-        e.partials = part + s.nb_main;
+      } else {
+        StepArgs e = base_args(c, s, src, !last);
+        e.y_begin = s.row0; e.y_count = 4; e.y_split = 2; e.y_begin2 = s.row0 + s.rows - 2;
+        e.partials = slot1 + s.nb_main;
         launch_step(c, e, s.nb_edge, s.s_edge);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(s.ev_edgek[q], s.s_edge));
-        // interior rows 1..rows-2: need the previous step's edge rows
-        HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
-        if (s.rows > 2) {
+        if (s.rows > 4) {
           StepArgs m = base_args(c, s, src, !last);
-          for (int k = 0; k < 3; k++) m.south_src[k] = m.north_src[k] = nullptr;  // never at a slab edge
-          m.y_begin = 1; m.y_count = s.rows - 2; m.y_step = 1;
-          m.partials = part;
+          m.y_begin = s.row0 + 2; m.y_count = s.rows - 4; m.y_split = m.y_count; m.y_begin2 = 0;
+          m.partials = slot1;
           launch_step(c, m, s.nb_main, s.s_main);
           HIP_TRY(hipGetLastError());
         } else {
-          HIP_TRY(hipMemsetAsync(part, 0, sizeof(float) * s.nb_main, s.s_main));
+          HIP_TRY(hipMemsetAsync(slot1, 0, sizeof(float) * s.nb_main, s.s_main));
         }
-        HIP_TRY(hipEventRecord(s.ev_main[q], s.s_main));
       }
-      if (!last)
-        if (int rc = exchange_halos(c, q)) return rc;
-      c->cur ^= 1;
-      c->ring_fill++;
-      if (c->ring_fill == c->ring || last)
-        if (int rc = flush(q)) return rc;
+      HIP_TRY(hipEventRecord(s.ev_edgek[q], s.s_edge));
+      HIP_TRY(hipEventRecord(s.ev_main[q], s.s_main));
     }
+    if (multi && !last)
+      if (int rc = exchange_halos(c, src ^ 1, q)) return rc;
+    c->cur ^= 1;
+    c->ring_fill += adv;
+    i += adv;
+    set++;
+    last_q = q;
   }
+  if (int rc = flush()) return rc;
   c->steps_done += nsteps;
 
   if (timed) {
@@ -544,10 +614,6 @@ void free_slab(Slab &s) {
   hipSetDevice(s.dev);
   for (int i = 0; i < 2; i++) {
     if (s.cells[i]) hipFree(s.cells[i]);
-    for (int j = 0; j < 2; j++) {
-      if (s.halo_send[i][j]) hipFree(s.halo_send[i][j]);
-      if (s.halo_recv[i][j]) hipFree(s.halo_recv[i][j]);
-    }
     if (s.ev_main[i]) hipEventDestroy(s.ev_main[i]);
     if (s.ev_edgek[i]) hipEventDestroy(s.ev_edgek[i]);
   }
@@ -555,7 +621,8 @@ void free_slab(Slab &s) {
   if (s.partials) hipFree(s.partials);
   if (s.av_sum) hipFree(s.av_sum);
   if (s.fin_partials) hipFree(s.fin_partials);
-  if (s.f_chunk_start) hipFree(s.f_chunk_start);
+  if (s.f_main.chunk_start) hipFree(s.f_main.chunk_start);
+  if (s.f_edge.chunk_start) hipFree(s.f_edge.chunk_start);
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
@@ -573,7 +640,7 @@ int check_params(const lbm_params *p) {
   return LBM_OK;
 }
 
-// Allocate and fill one slab (rows [y0, y0+rows) of the global grid).
+// Allocate and fill one slab (rows [y0, y0+rows) of the global grid, plus halo rows in slab mode).
 int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   const int nx = c->p.nx, ny = c->p.ny;
   const bool multi = c->nslabs_global > 1;
@@ -587,42 +654,39 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   HIP_TRY(hipEventCreate(&s.ev_t0));
   HIP_TRY(hipEventCreate(&s.ev_t1));
   HIP_TRY(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
-  const size_t n = (size_t)nx * s.rows;
+  s.row0 = multi ? 2 : 0;
+  s.ext_rows = s.rows + 2 * s.row0;
   // row-interleaved SoA (see d2q9_kernels.h): plane-rows padded to whole 256-B lines
   s.plane_stride = ((size_t)(nx + 63) / 64) * 64;
   const char *pad_env = getenv("LBM_ROW_PAD");  // extra floats between grid rows (tuning only)
   s.row_stride = 9 * s.plane_stride + (pad_env ? (size_t)atol(pad_env) / 4 * 4 : 0);
   for (int i = 0; i < 2; i++) {
-    if (dev_alloc(&s.cells[i], s.row_stride * s.rows + 64)) return LBM_ERR_HIP;
+    if (dev_alloc(&s.cells[i], s.row_stride * s.ext_rows + 64)) return LBM_ERR_HIP;
+    HIP_TRY(hipMemset(s.cells[i], 0, (s.row_stride * s.ext_rows + 64) * sizeof(float)));
   }
-  if (dev_alloc(&s.mask, n + 64)) return LBM_ERR_HIP;
+  const size_t n_ext = (size_t)nx * s.ext_rows;
+  if (dev_alloc(&s.mask, n_ext + 64)) return LBM_ERR_HIP;
   {
-    std::vector<uint8_t> m(n);
-    const int32_t *src = obstacles + (size_t)s.y0 * nx;
-    for (size_t i = 0; i < n; i++) m[i] = src[i] != 0;
-    HIP_TRY(hipMemcpy(s.mask, m.data(), n, hipMemcpyHostToDevice));
+    // stored row e holds global row (y0 - row0 + e) mod ny: halo rows carry the neighbours' obstacle flags
+    std::vector<uint8_t> m(n_ext);
+    for (int e = 0; e < s.ext_rows; e++) {
+      const int gy = ((s.y0 - s.row0 + e) % ny + ny) % ny;
+      const int32_t *src = obstacles + (size_t)gy * nx;
+      for (int x = 0; x < nx; x++) m[(size_t)e * nx + x] = src[x] != 0;
+    }
+    HIP_TRY(hipMemcpy(s.mask, m.data(), n_ext, hipMemcpyHostToDevice));
   }
-  const int ar = ny - 2;  // kernels.cl:18
-  s.accel_row = (ar >= s.y0 && ar < s.y0 + s.rows) ? ar - s.y0 : -1;
-  if (multi) {
-    s.nb_main = step_blocks(c, std::max(1, s.rows - 2));
-    s.nb_edge = step_blocks(c, 2);
-    for (int q = 0; q < 2; q++)
-      for (int d = 0; d < 2; d++) {
-        if (dev_alloc(&s.halo_send[q][d], (size_t)3 * nx)) return LBM_ERR_HIP;
-        if (dev_alloc(&s.halo_recv[q][d], (size_t)3 * nx)) return LBM_ERR_HIP;
-      }
-  } else {
-    s.nb_main = step_blocks(c, s.rows);
-    s.nb_edge = 0;
+  // the accelerated row ny-2 (kernels.cl:18) in stored-row coordinates
+  s.accel_own = s.accel_ext = -1;
+  for (int e = std::max(0, s.row0 - 1); e <= std::min(s.ext_rows - 1, s.row0 + s.rows); e++) {
+    const int gy = ((s.y0 - s.row0 + e) % ny + ny) % ny;
+    if (gy != ny - 2) continue;
+    if (e >= s.row0 && e < s.row0 + s.rows) s.accel_own = e;
+    if (multi || s.accel_own == e) s.accel_ext = e;
   }
-  s.nb_total = s.nb_main + s.nb_edge;
-  if (fuse_possible(c)) {
-    if (int rc = fuse_geometry(c, s)) return rc;
-    s.nb_total = std::max(s.nb_total, s.f_units);
-  }
+  if (!multi) s.accel_ext = s.accel_own;
   if (dev_alloc(&s.av_sum, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
-  s.fin_blocks = std::max(1, std::min(div_up((long)n, kBlock), 2048));
+  s.fin_blocks = std::max(1, std::min(div_up((long)nx * s.rows, kBlock), 2048));
   if (dev_alloc(&s.fin_partials, (size_t)s.fin_blocks)) return LBM_ERR_HIP;
   return LBM_OK;
 }
@@ -642,30 +706,12 @@ int alloc_partials(lbm_ctx *c) {
   return LBM_OK;
 }
 
-void split_rows(int ny, int P, int idx, int *y0, int *rows) {
-  const int base = ny / P, rem = ny % P;
-  *y0 = idx * base + std::min(idx, rem);
-  *rows = base + (idx < rem ? 1 : 0);
-}
-
 int rebuild_geometry(lbm_ctx *c) {
-  // grid_blocks / variant changes alter the number of partial sums per step
-  const bool multi = c->nslabs_global > 1;
+  // grid_blocks / chunk changes alter the number of partial sums per step
   for (Slab &s : c->slabs) {
     if (set_dev(s)) return LBM_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(s.s_main));
-    if (multi) {
-      s.nb_main = step_blocks(c, std::max(1, s.rows - 2));
-      s.nb_edge = step_blocks(c, 2);
-    } else {
-      s.nb_main = step_blocks(c, s.rows);
-      s.nb_edge = 0;
-    }
-    s.nb_total = s.nb_main + s.nb_edge;
-    if (fuse_possible(c)) {
-      if (int rc = fuse_geometry(c, s)) return rc;
-      s.nb_total = std::max(s.nb_total, s.f_units);
-    }
+    if (int rc = slab_geometry(c, s)) return rc;
   }
   return alloc_partials(c);
 }
@@ -697,8 +743,8 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
   if (int rc = check_params(params)) return rc;
   if (!obstacles) return fail(LBM_ERR_ARG, "obstacles is NULL");
   if (nslabs_global < 1) return fail(LBM_ERR_ARG, "need at least one slab");
-  if (nslabs_global > 1 && params->ny / nslabs_global < 2)
-    return fail(LBM_ERR_ARG, "ny=%d gives fewer than 2 rows per slab over %d slabs", params->ny, nslabs_global);
+  if (nslabs_global > 1 && params->ny / nslabs_global < 4)
+    return fail(LBM_ERR_ARG, "ny=%d gives fewer than 4 rows per slab over %d slabs", params->ny, nslabs_global);
   int ndev_visible = 0;
   HIP_TRY(hipGetDeviceCount(&ndev_visible));
   if (ndev_visible < 1) return fail(LBM_ERR_HIP, "no HIP device visible");
@@ -720,6 +766,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     split_rows(params->ny, nslabs_global, s.index, &s.y0, &s.rows);
     rc = build_slab(c, s, obstacles);
   }
+  for (size_t i = 0; i < c->slabs.size() && rc == LBM_OK; i++) rc = slab_geometry(c, c->slabs[i]);
   if (rc == LBM_OK) rc = alloc_partials(c);
   // transport for halo exchange
   if (rc == LBM_OK && nslabs_global > 1) {
@@ -815,13 +862,13 @@ int lbm_upload(lbm_ctx *c, const float *cells) {
     if (cells) {
       // reference SoA plane k (d2q9-bgk.c:73) -> plane-row k of every grid row
       for (int k = 0; k < 9; k++)
-        HIP_TRY(hipMemcpy2DAsync(s.cells[0] + k * s.plane_stride, s.row_stride * sizeof(float),
+        HIP_TRY(hipMemcpy2DAsync(s.own(0) + k * s.plane_stride, s.row_stride * sizeof(float),
                                  cells + k * n_global + (size_t)s.y0 * nx, (size_t)nx * sizeof(float),
                                  (size_t)nx * sizeof(float), s.rows, hipMemcpyHostToDevice, s.s_main));
     } else {
       // d2q9-bgk.c:529-531
       const float w0 = c->p.density * 4.0f / 9.0f, w1 = c->p.density / 9.0f, w2 = c->p.density / 36.0f;
-      hipLaunchKernelGGL(init_cells, dim3(std::min(div_up((long)n, 256), 4096)), dim3(256), 0, s.s_main, s.cells[0],
+      hipLaunchKernelGGL(init_cells, dim3(std::min(div_up((long)n, 256), 4096)), dim3(256), 0, s.s_main, s.own(0),
                          s.plane_stride, s.row_stride, nx, n, w0, w1, w2);
       HIP_TRY(hipGetLastError());
     }
@@ -872,7 +919,7 @@ int lbm_download(lbm_ctx *c, float *cells_out, float *av_vels_out) {
       if (set_dev(s)) return LBM_ERR_HIP;
       for (int k = 0; k < 9; k++)
         HIP_TRY(hipMemcpy2DAsync(cells_out + k * n_global + (size_t)s.y0 * nx, (size_t)nx * sizeof(float),
-                                 s.cells[c->cur] + k * s.plane_stride, s.row_stride * sizeof(float),
+                                 s.own(c->cur) + k * s.plane_stride, s.row_stride * sizeof(float),
                                  (size_t)nx * sizeof(float), s.rows, hipMemcpyDeviceToHost, s.s_main));
       HIP_TRY(hipStreamSynchronize(s.s_main));
     }
@@ -919,8 +966,8 @@ int lbm_final_state(lbm_ctx *c, float *u_x, float *u_y, float *u, float *pressur
     float *d[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; i++)
       if (outs[i] && dev_alloc(&d[i], n)) return LBM_ERR_HIP;
-    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.cells[c->cur], s.plane_stride,
-                       s.row_stride, nx, s.mask, n, c->p.density, d[0], d[1], d[2], d[3], s.fin_partials);
+    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.own(c->cur), s.plane_stride,
+                       s.row_stride, nx, s.mask_own(nx), n, c->p.density, d[0], d[1], d[2], d[3], s.fin_partials);
     hipError_t e = hipGetLastError();
     for (int i = 0; i < 4 && e == hipSuccess; i++)
       if (outs[i]) e = hipMemcpyAsync(outs[i] + (size_t)s.y0 * nx, d[i], n * sizeof(float), hipMemcpyDeviceToHost, s.s_main);
@@ -939,8 +986,8 @@ int lbm_reynolds(lbm_ctx *c, float *reynolds_out) {
   for (Slab &s : c->slabs) {
     if (set_dev(s)) return LBM_ERR_HIP;
     const size_t n = (size_t)c->p.nx * s.rows;
-    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.cells[c->cur], s.plane_stride,
-                       s.row_stride, c->p.nx, s.mask, n, c->p.density, (float *)nullptr, (float *)nullptr, (float *)nullptr,
+    hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.own(c->cur), s.plane_stride,
+                       s.row_stride, c->p.nx, s.mask_own(c->p.nx), n, c->p.density, (float *)nullptr, (float *)nullptr, (float *)nullptr,
                        (float *)nullptr, s.fin_partials);
     HIP_TRY(hipGetLastError());
     std::vector<float> part(s.fin_blocks);
@@ -1000,8 +1047,8 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "grid_blocks")) *value = c->slabs.empty() ? 0 : c->slabs[0].nb_main;
   else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
   else if (!strcmp(key, "fuse")) *value = fuse_effective(c);
-  else if (!strcmp(key, "chunk_rows")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_chunk;
-  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_units;
+  else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
+  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_main.units + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "use_graph")) *value = c->use_graph;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;

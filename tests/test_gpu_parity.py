@@ -227,18 +227,32 @@ def test_final_state_and_reynolds(lbm, oracle_f32):
 
 # ---- row partition on one GPU (several slabs on device 0, halos by device-to-device copies) ----------
 
-@pytest.mark.parametrize("nslabs", [2, 3, 8])
-def test_row_slabs_equal_single_slab(lbm, nslabs):
+@pytest.mark.parametrize("nslabs,ny", [(2, 50), (3, 50), (8, 50), (2, 16), (4, 67), (5, 128)])
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_row_slabs_equal_single_slab(lbm, nslabs, ny, fuse):
+    """several slabs on one GPU (halo rows exchanged by device-to-device copies) against one slab, with one
+    and with two timesteps per launch; 37 steps = 18 two-step launch sets + one single step"""
     rng = np.random.default_rng(5)
-    nx, ny, nsteps = 256, 50, 37
+    nx, nsteps = 256, 37
     ob, cells0 = random_case(rng, nx, ny)
     ob[0, :] = 0
     ob[-1, :] = 0  # open top/bottom: the y wrap-around between the last and the first slab carries flow
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
-    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps)
-    many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, devices=[0] * nslabs)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 0})
+    many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": fuse}, devices=[0] * nslabs)
     assert np.array_equal(one, many)                 # per-cell arithmetic is identical
     assert max_rel(av_many, av_one) < 2e-6           # only the summation order of av_vels differs
+
+
+def test_row_slabs_large_fused(lbm):
+    """2048x512 over 4 slabs with the two-step kernel's edge/interior split and tapered schedule"""
+    rng = np.random.default_rng(9)
+    nx, ny, nsteps = 2048, 512, 11
+    ob, cells0 = random_case(rng, nx, ny, blocked=0.02)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 0})
+    many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 1}, devices=[0, 0, 0, 0])
+    assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
 
 
 def test_row_slabs_split_runs_and_shipped_geometry(lbm, oracle_f32_omp):
