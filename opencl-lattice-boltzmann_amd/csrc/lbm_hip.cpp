@@ -147,6 +147,7 @@ struct lbm_ctx {
   std::vector<Slab> slabs;  // local slabs
   int nslabs_global = 1;    // slabs in the ring (== slabs.size() unless rank mode)
   bool rank_mode = false;
+  bool halo_mode = false;   // slabs carry halo rows and exchange them (more than one slab, or forced for tests)
   int rank = 0;
   int cur = 0;              // index of the grid holding the current state
   int steps_done = 0;
@@ -263,7 +264,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
 
 // All launch geometry of a slab (single-step workgroup counts, fused schedules, ring slot stride).
 int slab_geometry(const lbm_ctx *c, Slab &s) {
-  const bool multi = c->nslabs_global > 1;
+  const bool multi = c->halo_mode;
   if (multi) {
     // single-step kernel in slab mode: 2 bottom + 2 top rows first (what the neighbours receive), then the rest
     s.nb_edge = step_blocks(c, 4);
@@ -444,7 +445,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
                 c->steps_done, nsteps);
   if (timed && ms) *ms = 0.0;
   if (nsteps == 0) return LBM_OK;
-  const bool multi = c->nslabs_global > 1;
+  const bool multi = c->halo_mode;
   const bool fuse = fuse_effective(c);
   const float aw1 = c->p.density * c->p.accel / 9.0f, aw2 = c->p.density * c->p.accel / 36.0f;
   const int nx = c->p.nx;
@@ -643,7 +644,7 @@ int check_params(const lbm_params *p) {
 // Allocate and fill one slab (rows [y0, y0+rows) of the global grid, plus halo rows in slab mode).
 int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   const int nx = c->p.nx, ny = c->p.ny;
-  const bool multi = c->nslabs_global > 1;
+  const bool multi = c->halo_mode;
   if (set_dev(s)) return LBM_ERR_HIP;
   HIP_TRY(hipStreamCreateWithFlags(&s.s_main, hipStreamNonBlocking));
   if (multi) HIP_TRY(hipStreamCreateWithFlags(&s.s_edge, hipStreamNonBlocking));
@@ -743,7 +744,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
   if (int rc = check_params(params)) return rc;
   if (!obstacles) return fail(LBM_ERR_ARG, "obstacles is NULL");
   if (nslabs_global < 1) return fail(LBM_ERR_ARG, "need at least one slab");
-  if (nslabs_global > 1 && params->ny / nslabs_global < 4)
+  if ((nslabs_global > 1 || (getenv("LBM_FORCE_HALO") && atoi(getenv("LBM_FORCE_HALO")))) && params->ny / nslabs_global < 4)
     return fail(LBM_ERR_ARG, "ny=%d gives fewer than 4 rows per slab over %d slabs", params->ny, nslabs_global);
   int ndev_visible = 0;
   HIP_TRY(hipGetDeviceCount(&ndev_visible));
@@ -754,6 +755,10 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
   lbm_ctx *c = new lbm_ctx();
   c->p = *params;
   c->nslabs_global = nslabs_global;
+  // LBM_FORCE_HALO=1 runs even a single slab through the halo-exchange machinery (a ring of one: the slab
+  // is its own north and south neighbour) — lets a 1-GPU box exercise the RCCL transport end to end
+  const char *force = getenv("LBM_FORCE_HALO");
+  c->halo_mode = nslabs_global > 1 || (force && atoi(force) != 0);
   c->rank_mode = rank_mode;
   c->rank = rank;
   c->vec4 = (params->nx % 4 == 0);
@@ -769,7 +774,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
   for (size_t i = 0; i < c->slabs.size() && rc == LBM_OK; i++) rc = slab_geometry(c, c->slabs[i]);
   if (rc == LBM_OK) rc = alloc_partials(c);
   // transport for halo exchange
-  if (rc == LBM_OK && nslabs_global > 1) {
+  if (rc == LBM_OK && c->halo_mode) {
     bool dup = false;
     for (size_t i = 0; i < devs.size(); i++)
       for (size_t j = i + 1; j < devs.size(); j++) dup |= devs[i] == devs[j];
@@ -777,7 +782,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     int want = TRANSPORT_AUTO;
     if (env && !strcmp(env, "rccl")) want = TRANSPORT_RCCL;
     if (env && !strcmp(env, "copy")) want = TRANSPORT_COPY;
-    if (rank_mode) c->transport_eff = TRANSPORT_RCCL;
+    if (rank_mode) c->transport_eff = (want == TRANSPORT_COPY && nslabs_global == 1) ? TRANSPORT_COPY : TRANSPORT_RCCL;
     else if (want == TRANSPORT_AUTO) c->transport_eff = dup ? TRANSPORT_COPY : TRANSPORT_RCCL;
     else c->transport_eff = want;
     if (c->transport_eff == TRANSPORT_RCCL && !rank_mode && dup) {
@@ -848,7 +853,8 @@ int lbm_create_rank(lbm_ctx **out, const lbm_params *params, const int32_t *obst
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(LBM_ERR_ARG, "bad rank %d of %d", rank, nranks);
   if (nranks > 1 && !comm_id) return fail(LBM_ERR_ARG, "comm_id is NULL");
   std::vector<int> idx{rank}, devs{device};
-  return create_common(out, params, obstacles, nranks, idx, devs, nranks > 1, rank, comm_id);
+  // rank mode proper needs a communicator; a single rank gets one too when an id is supplied (self-ring tests)
+  return create_common(out, params, obstacles, nranks, idx, devs, nranks > 1 || comm_id != nullptr, rank, comm_id);
 }
 
 int lbm_upload(lbm_ctx *c, const float *cells) {
@@ -927,7 +933,7 @@ int lbm_download(lbm_ctx *c, float *cells_out, float *av_vels_out) {
   if (av_vels_out && c->steps_done > 0) {
     const int T = c->steps_done;
     std::vector<double> total(T, 0.0);
-    if (c->rank_mode && c->nslabs_global > 1) {
+    if (c->rank_mode && c->halo_mode && c->transport_eff == TRANSPORT_RCCL) {
       // combine the per-rank velocity sums: one all-reduce over the whole record
       Slab &s = c->slabs[0];
       if (set_dev(s)) return LBM_ERR_HIP;
@@ -995,7 +1001,7 @@ int lbm_reynolds(lbm_ctx *c, float *reynolds_out) {
     HIP_TRY(hipStreamSynchronize(s.s_main));
     for (float v : part) tot += v;
   }
-  if (c->rank_mode && c->nslabs_global > 1) {
+  if (c->rank_mode && c->halo_mode && c->transport_eff == TRANSPORT_RCCL) {
     Slab &s = c->slabs[0];
     double *tmp = nullptr;
     if (dev_alloc(&tmp, 2)) return LBM_ERR_HIP;

@@ -244,6 +244,18 @@ def test_row_slabs_equal_single_slab(lbm, nslabs, ny, fuse):
     assert max_rel(av_many, av_one) < 2e-6           # only the summation order of av_vels differs
 
 
+@pytest.mark.parametrize("transport", ["copy", "rccl"])
+def test_rccl_transport_self_ring(transport):
+    """the halo-exchange machinery with ONE slab that is its own ring neighbour; with transport=rccl every
+    exchange is ncclSend/ncclRecv (to self) on a communicator made by ncclCommInitRank and av_vels go through
+    ncclAllReduce — the code path of the one-process-per-GPU launch, exercised on a single GPU"""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_self_ring.py"), transport],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "self-ring ok" in r.stdout
+
+
 def test_row_slabs_large_fused(lbm):
     """2048x512 over 4 slabs with the two-step kernel's edge/interior split and tapered schedule"""
     rng = np.random.default_rng(9)
