@@ -1036,6 +1036,14 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   }
   if (!strcmp(key, "nt_stores")) { c->nt_stores = (int)value; return LBM_OK; }
   if (!strcmp(key, "fuse")) { c->fuse = (int)value; return LBM_OK; }
+  if (!strcmp(key, "vec")) {
+    // cells per thread of the single-step kernel: 4 (float4 rows) or 1
+    if (value != 1 && value != 4) return fail(LBM_ERR_ARG, "vec must be 1 or 4");
+    if (value == 4 && c->p.nx % 4 != 0) return fail(LBM_ERR_ARG, "vec=4 needs nx %% 4 == 0");
+    if (int rc = sync_all(c)) return rc;
+    c->vec4 = (value == 4);
+    return rebuild_geometry(c);
+  }
   if (!strcmp(key, "chunk_rows") || !strcmp(key, "chunk_min")) {
     if (value < 0) return fail(LBM_ERR_ARG, "%s must be >= 0", key);
     if (int rc = sync_all(c)) return rc;
