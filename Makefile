@@ -20,7 +20,7 @@ $(LIB): $(PKG)/csrc/lbm_hip.cpp $(PKG)/csrc/d2q9_kernels.h include/lbm.h
 	$(HIPCC) $(HIPFLAGS) -shared $(PKG)/csrc/lbm_hip.cpp -o $@ -ldl
 
 $(EXE): $(PKG)/host/d2q9-bgk.c include/lbm.h $(LIB)
-	$(CC) -std=c99 -O2 -Wall -D_GNU_SOURCE -Iinclude $(PKG)/host/d2q9-bgk.c -o $@ -L$(PKG) -llbm_hip -lm -Wl,-rpath,'$$ORIGIN/$(PKG)'
+	$(CC) -std=c99 -O2 -Wall -D_GNU_SOURCE -Iinclude $(PKG)/host/d2q9-bgk.c -o $@ -L$(PKG) -llbm_hip -lm -lpthread -Wl,-rpath,'$$ORIGIN/$(PKG)'
 
 $(EXE).exe: $(EXE)
 	cp $(EXE) $(EXE).exe

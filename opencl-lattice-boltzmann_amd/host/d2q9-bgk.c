@@ -21,6 +21,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -188,20 +189,77 @@ static void load_obstacles(const char *obstaclefile, lbm_params *params, int32_t
 }
 
 /* ---- output stage: d2q9-bgk.c:772-856 ---------------------------------------------------------- */
+/* Same bytes as the reference's fprintf loop (d2q9-bgk.c:835: "%d %d %.12E %.12E %.12E %.12E %d\n"), but the
+ * rows of a block are formatted by several threads into memory and written with one fwrite per thread
+ * buffer: the 1024x1024 file (1 M lines, 90 MB) takes tens of milliseconds instead of about a second. */
+
+#define LINE_MAX_BYTES 128 /* 2 ints (<= 11 chars) + 4 x 19 chars + flag + separators */
+
+typedef struct {
+  const lbm_params *params;
+  const float *u_x, *u_y, *u, *pressure;
+  const int32_t *obstacles;
+  int row_begin, row_end;
+  char *buf;
+  size_t len;
+} format_job;
+
+static void *format_rows(void *arg)
+{
+  format_job *j = (format_job *)arg;
+  const int nx = j->params->nx;
+  char *p = j->buf;
+  for (int ii = j->row_begin; ii < j->row_end; ii++) {
+    for (int jj = 0; jj < nx; jj++) {
+      const size_t c = (size_t)ii * nx + jj;
+      p += sprintf(p, "%d %d %.12E %.12E %.12E %.12E %d\n", jj, ii, j->u_x[c], j->u_y[c], j->u[c], j->pressure[c],
+                   j->obstacles[c]);
+    }
+  }
+  j->len = (size_t)(p - j->buf);
+  return NULL;
+}
 
 static int write_values(const lbm_params *params, const float *u_x, const float *u_y, const float *u,
                         const float *pressure, const int32_t *obstacles, const float *av_vels)
 {
   FILE *fp = fopen(FINALSTATEFILE, "w");
   if (fp == NULL) die("could not open file output file", __LINE__, __FILE__);
-  static char iobuf[1 << 20];
-  setvbuf(fp, iobuf, _IOFBF, sizeof iobuf);
-  for (int ii = 0; ii < params->ny; ii++) {
-    for (int jj = 0; jj < params->nx; jj++) {
-      const size_t c = (size_t)ii * params->nx + jj;
-      fprintf(fp, "%d %d %.12E %.12E %.12E %.12E %d\n", jj, ii, u_x[c], u_y[c], u[c], pressure[c], obstacles[c]);
+  long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+  int nthreads = (int)(ncpu < 1 ? 1 : (ncpu > 16 ? 16 : ncpu));
+  if (getenv("LBM_WRITER_THREADS")) nthreads = atoi(getenv("LBM_WRITER_THREADS"));
+  if (nthreads < 1) nthreads = 1;
+  /* rows per thread and block: at most ~32 MB of text per thread in flight */
+  int rows_per_job = (int)((32u << 20) / ((size_t)params->nx * LINE_MAX_BYTES));
+  if (rows_per_job < 1) rows_per_job = 1;
+  format_job *jobs = (format_job *)calloc((size_t)nthreads, sizeof(format_job));
+  pthread_t *tids = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+  if (!jobs || !tids) die("cannot allocate memory for the output writer", __LINE__, __FILE__);
+  for (int t = 0; t < nthreads; t++) {
+    jobs[t].buf = (char *)malloc((size_t)rows_per_job * params->nx * LINE_MAX_BYTES + 1);
+    if (!jobs[t].buf) die("cannot allocate memory for the output writer", __LINE__, __FILE__);
+  }
+  for (int row = 0; row < params->ny;) {
+    int used = 0;
+    for (int t = 0; t < nthreads && row < params->ny; t++, used++) {
+      format_job *j = &jobs[t];
+      j->params = params; j->u_x = u_x; j->u_y = u_y; j->u = u; j->pressure = pressure; j->obstacles = obstacles;
+      j->row_begin = row;
+      j->row_end = row + rows_per_job < params->ny ? row + rows_per_job : params->ny;
+      row = j->row_end;
+      if (pthread_create(&tids[t], NULL, format_rows, j) != 0) {  /* no threads available: format inline */
+        format_rows(j);
+        tids[t] = 0;
+      }
+    }
+    for (int t = 0; t < used; t++) {
+      if (tids[t]) pthread_join(tids[t], NULL);
+      if (fwrite(jobs[t].buf, 1, jobs[t].len, fp) != jobs[t].len) die("could not write output file", __LINE__, __FILE__);
     }
   }
+  for (int t = 0; t < nthreads; t++) free(jobs[t].buf);
+  free(jobs);
+  free(tids);
   fclose(fp);
 
   fp = fopen(AVVELSFILE, "w");

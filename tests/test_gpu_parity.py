@@ -334,10 +334,20 @@ def test_c_host_end_to_end(tmp_path):
                         "--av-vels-file=" + str(tmp_path / "av_vels.dat"),
                         "--final-state-file=" + str(tmp_path / "final_state.dat")], capture_output=True, text=True)
     assert c.returncode == 0 and "Both tests passed!" in c.stdout, c.stdout
-    # several slabs from the environment, same answer through the checker
+    # the multi-threaded writer produces the same bytes as a single thread, in the reference's line format
+    first = open(tmp_path / "final_state.dat", "rb").read()
+    import re
+    assert re.fullmatch(rb"\d+ \d+ -?\d\.\d{12}E[+-]\d\d -?\d\.\d{12}E[+-]\d\d \d\.\d{12}E[+-]\d\d \d\.\d{12}E[+-]\d\d [01]",
+                        first.split(b"\n")[130])
+    assert first.count(b"\n") == 128 * 128
+    env = dict(os.environ, LBM_WRITER_THREADS="1")
+    r = subprocess.run([exe, *input_files("128x128")], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and open(tmp_path / "final_state.dat", "rb").read() == first
+    # several slabs from the environment, same answer
     env = dict(os.environ, LBM_DEVICES="0,0")
     r = subprocess.run([exe, *input_files("128x128")], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
+    assert open(tmp_path / "final_state.dat", "rb").read() == first
 
 
 # ---- full benchmark size: properties that need no full-size oracle run ------------------------------------

@@ -124,7 +124,7 @@ int main(int argc, char **argv) {
             a.north_src[k] = buf[cur] + np[k] * ps;
           }
           a.partials = partials; a.plane_stride = ps; a.row_stride = rs; a.nx = nx; a.rows = ny;
-          a.y_begin = 0; a.y_count = ny; a.y_step = 1; a.accel_row = ny - 2;
+          a.y_begin = 0; a.y_count = ny; a.y_split = ny; a.y_begin2 = 0; a.accel_row = ny - 2;
           a.omega = 1.85f; a.aw1 = 0.1f * 0.005f / 9.f; a.aw2 = 0.1f * 0.005f / 36.f;
           switch (v.mode) {
             case 0: launch_lm<LM_SCALAR>(v.nt, v.blocks, st, a); break;
@@ -173,7 +173,7 @@ int main(int argc, char **argv) {
         a.north_src[k] = buf[cur] + np[k] * ps;
       }
       a.partials = partials; a.plane_stride = ps; a.row_stride = rs; a.nx = nx; a.rows = ny;
-      a.y_begin = 0; a.y_count = ny; a.y_step = 1; a.accel_row = ny - 2;
+      a.y_begin = 0; a.y_count = ny; a.y_split = ny; a.y_begin2 = 0; a.accel_row = ny - 2;
       a.omega = 1.85f; a.aw1 = 0.1f * 0.005f / 9.f; a.aw2 = 0.1f * 0.005f / 36.f;
       switch (v.mode) {
         case 0: launch_lm<LM_SCALAR>(v.nt, v.blocks, st, a); break;
