@@ -127,6 +127,8 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  2 = unaligned 16-byte loads, 3 = wave64 DPP shifts, 4 = LDS-staged row with halo
  *   "fuse"         1 = advance two timesteps per launch (intermediate state kept in registers, half
  *                  the HBM traffic), 0 = one launch per step, -1 = auto.  Single-slab grids only.
+ *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
+ *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)
  *   "chunk_min"    fewest rows per wave at the tapered end of the schedule (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)

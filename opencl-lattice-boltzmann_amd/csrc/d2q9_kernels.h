@@ -519,6 +519,118 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   }
 }
 
+// ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------
+// Grids of a few hundred cells a side are bound by launch latency, not bandwidth (one step of 128x128 is
+// ~2 us of work behind ~3.4 us of launch cost).  This kernel advances T <= kMultiMaxT steps per launch: a
+// workgroup loads a (kMultiTX + 2T) x (kMultiTY + 2T) region around its output tile into LDS, performs T
+// stream+collide steps LDS -> LDS on a region that shrinks by one cell per step (halo cells are computed
+// redundantly by the neighbouring tiles), and stores the central tile.  Same per-cell arithmetic
+// (collide_cell / accelerate_cell) as the other kernels, so the results are bit-identical.
+constexpr int kMultiMaxT = 8;
+constexpr int kMultiTX = 32, kMultiTY = 16;
+constexpr int kMultiRX = kMultiTX + 2 * kMultiMaxT, kMultiRY = kMultiTY + 2 * kMultiMaxT;  // 48 x 32
+constexpr int kMultiThreads = 1024;
+
+struct MultiArgs {
+  const float *src;
+  float *dst;
+  const uint8_t *mask;
+  float *partials;          // [T][partials_stride]: per-tile sums of |j|/rho for each of the T steps
+  unsigned long long plane_stride, row_stride, partials_stride;
+  int nx, ny;
+  int tiles_x, tiles_y;
+  int T;                    // steps in this launch
+  int accel_row;            // ny-2
+  int accel_next;           // apply the following step's accelerate_flow to the final state
+  float omega, aw1, aw2;
+};
+
+__global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
+  __shared__ float lds[2][9][kMultiRY * kMultiRX];
+  __shared__ uint8_t lmask[kMultiRY * kMultiRX];
+  __shared__ float wsum[kMultiMaxT][kMultiThreads / 64];
+  const int tid = threadIdx.x;
+  const int T = a.T;
+  const int RX = kMultiTX + 2 * T, RY = kMultiTY + 2 * T;
+  const int tile_y = blockIdx.x / a.tiles_x, tile_x = blockIdx.x - tile_y * a.tiles_x;
+  const int gx0 = tile_x * kMultiTX - T, gy0 = tile_y * kMultiTY - T;  // global coordinates of region cell (0,0)
+  const size_t ps = a.plane_stride;
+
+  // region -> LDS (periodic wrap in both directions, kernels.cl:91-102)
+  {
+    const float inv = 1.0f / (float)RX;
+    for (int i = tid; i < RX * RY; i += kMultiThreads) {
+      const int ry = (int)(((float)i + 0.5f) * inv), rx = i - ry * RX;
+      int gx = (gx0 + rx) % a.nx, gy = (gy0 + ry) % a.ny;
+      if (gx < 0) gx += a.nx;
+      if (gy < 0) gy += a.ny;
+      const float *p = a.src + (size_t)gy * a.row_stride + gx;
+#pragma unroll
+      for (int k = 0; k < 9; k++) lds[0][k][ry * kMultiRX + rx] = p[k * ps];
+      lmask[ry * kMultiRX + rx] = a.mask[(size_t)gy * a.nx + gx];
+    }
+  }
+  __syncthreads();
+
+  for (int s = 1; s <= T; s++) {
+    const int in = (s - 1) & 1, out = s & 1;
+    const int w = RX - 2 * s, h = RY - 2 * s;
+    const float inv = 1.0f / (float)w;
+    const bool accel_step = (s < T) || a.accel_next;
+    float sum = 0.f;
+    for (int i = tid; i < w * h; i += kMultiThreads) {
+      const int q = (int)(((float)i + 0.5f) * inv);
+      const int rx = s + (i - q * w), ry = s + q;
+      const int c = ry * kMultiRX + rx;
+      float g[9], o[9];
+      g[0] = lds[in][0][c];
+      g[1] = lds[in][1][c - 1];
+      g[2] = lds[in][2][c - kMultiRX];
+      g[3] = lds[in][3][c + 1];
+      g[4] = lds[in][4][c + kMultiRX];
+      g[5] = lds[in][5][c - kMultiRX - 1];
+      g[6] = lds[in][6][c - kMultiRX + 1];
+      g[7] = lds[in][7][c + kMultiRX + 1];
+      g[8] = lds[in][8][c + kMultiRX - 1];
+      const bool obst = lmask[c] != 0;
+      const float t = collide_cell(g, obst, a.omega, o);
+      int gy = (gy0 + ry) % a.ny;
+      if (gy < 0) gy += a.ny;
+      if (gy == a.accel_row && accel_step) accelerate_cell(o, obst, a.aw1, a.aw2);
+#pragma unroll
+      for (int k = 0; k < 9; k++) lds[out][k][c] = o[k];
+      // only the tile's own cells count (and, for tiles hanging over the grid edge, only real cells)
+      const int ox = rx - T, oy = ry - T;
+      if (ox >= 0 && ox < kMultiTX && oy >= 0 && oy < kMultiTY && tile_x * kMultiTX + ox < a.nx &&
+          tile_y * kMultiTY + oy < a.ny)
+        sum += t;
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) wsum[s - 1][tid >> 6] = sum;
+    __syncthreads();
+  }
+
+  // central tile -> global
+  {
+    const int fin = T & 1;
+    for (int i = tid; i < kMultiTX * kMultiTY; i += kMultiThreads) {
+      const int oy = i / kMultiTX, ox = i - oy * kMultiTX;
+      const int gx = tile_x * kMultiTX + ox, gy = tile_y * kMultiTY + oy;
+      if (gx < a.nx && gy < a.ny) {
+        const int c = (oy + T) * kMultiRX + ox + T;
+        float *d = a.dst + (size_t)gy * a.row_stride + gx;
+#pragma unroll
+        for (int k = 0; k < 9; k++) d[k * ps] = lds[fin][k][c];
+      }
+    }
+  }
+  if (tid < T) {
+    float t = wsum[tid][0];
+    for (int i = 1; i < kMultiThreads / 64; i++) t += wsum[tid][i];
+    a.partials[(size_t)tid * a.partials_stride + blockIdx.x] = t;
+  }
+}
+
 // ---- second reduction stage ------------------------------------------------------------------
 // One workgroup per buffered step: sums that step's per-workgroup partials in a fixed order into
 // av_sum[first + blockIdx.x] (double).  Replaces the reference's multi-pass reduce kernel

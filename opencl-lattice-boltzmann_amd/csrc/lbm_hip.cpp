@@ -126,6 +126,7 @@ struct Slab {
   int strips = 0, lanes_out = 0;  // x decomposition of d2q9_step2
   FuseGeom f_main, f_edge;        // whole slab (one slab) or interior chunks; the two edge chunks
   int edge_rows = 0;              // rows per edge chunk in slab mode
+  int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
   double *av_sum = nullptr;   // [capacity] per-step sum of |j|/rho over this slab's fluid cells
   hipStream_t s_main = nullptr, s_edge = nullptr;
   hipEvent_t ev_main[2] = {nullptr, nullptr};   // interior launch of a launch set done
@@ -161,6 +162,7 @@ struct lbm_ctx {
   int nt_stores = -1;
   int use_graph = -1;
   int fuse = -1;            // two timesteps per launch (d2q9_step2): -1 auto, 0 off, 1 on
+  int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
   int chunk_min = 0;        // shortest chunk at the tapered end of a band (0 = auto)
   bool vec4 = true;
@@ -215,6 +217,15 @@ bool fuse_effective(const lbm_ctx *c) {
   // auto: measured break-even on MI355X is just below 1024x1024 (99 vs 79 GLUPS there, 42 vs 46 at 512x512:
   // small grids have too few strip x chunk units to fill 2048 wave slots)
   return (long)c->p.nx * c->slabs[0].rows >= 768L * 1024;
+}
+
+// LDS multi-step kernel: one slab holding the whole periodic grid; worth it only while the grid is launch-bound
+int multistep_effective(const lbm_ctx *c) {
+  if (c->halo_mode) return 0;
+  if (c->multistep >= 0) return std::min(c->multistep, kMultiMaxT);
+  // auto: up to ~512x512 (measured: 1.6-1.8 us/step against 3.4-5.7 us for one launch per step); beyond that
+  // the tiles no longer fit one round of workgroups and the bandwidth-oriented kernels win
+  return ((long)c->p.nx * c->p.ny <= 300L * 1024) ? kMultiMaxT : 0;
 }
 
 // Work decomposition of d2q9_step2 over stored rows [r0, r1): strips x chunks.  A unit's cost is
@@ -274,6 +285,11 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     s.nb_edge = 0;
   }
   s.nb_total = s.nb_main + s.nb_edge;
+  if (!multi) {
+    s.m_tiles_x = div_up(c->p.nx, kMultiTX);
+    s.m_tiles_y = div_up(s.rows, kMultiTY);
+    if ((long)s.m_tiles_x * s.m_tiles_y <= 65536) s.nb_total = std::max(s.nb_total, s.m_tiles_x * s.m_tiles_y);
+  }
   if (fuse_possible(c)) {
     const int q4 = c->p.nx / 4;
     s.strips = div_up(q4, 62);  // lanes 0 and 63 of every wave are halo lanes
@@ -483,8 +499,10 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     }
 
   int batch_first = c->steps_done;
-  int batch_kind = 0;  // 1 = single-step launches, 2 = two-step launches in the current batch of the ring
+  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3 };
+  int batch_kind = KIND_NONE;  // launch kind of the steps buffered in the ring (their slot occupancy differs)
   int last_q = 1;
+  const int multi_T = multistep_effective(c);
   // second reduction stage over the buffered steps of all slabs (kernels.cl:234-290 counterpart)
   auto flush = [&]() -> int {
     const int fill = c->ring_fill;
@@ -492,7 +510,9 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
       if (multi) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[last_q], 0));
-      const int used = batch_kind == 2 ? s.f_main.units + (multi ? s.f_edge.units : 0) : s.nb_main + s.nb_edge;
+      int used = s.nb_main + s.nb_edge;
+      if (batch_kind == KIND_FUSED2) used = s.f_main.units + (multi ? s.f_edge.units : 0);
+      if (batch_kind == KIND_MULTI) used = s.m_tiles_x * s.m_tiles_y;
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
       HIP_TRY(hipGetLastError());
@@ -510,18 +530,46 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
   int i = 0, set = 0;
   while (i < nsteps) {
     const int src = c->cur;
-    const int adv = (fuse && nsteps - i >= 2) ? 2 : 1;  // timesteps advanced by this launch set
+    // timesteps advanced by this launch set, and with which kernel
+    int kind = KIND_SINGLE, adv = 1;
+    if (multi_T > 0 && !multi && c->slabs[0].m_tiles_x * (long)c->slabs[0].m_tiles_y <= 65536) {
+      kind = KIND_MULTI;
+      adv = std::min(multi_T, nsteps - i);
+    } else if (fuse && nsteps - i >= 2) {
+      kind = KIND_FUSED2;
+      adv = 2;
+    }
     const bool last = (i + adv == nsteps);
     const int q = set & 1, qp = q ^ 1;  // event parity of this launch set / of the previous one
-    if (batch_kind != adv || c->ring_fill + adv > c->ring)
+    if (batch_kind != kind || c->ring_fill + adv > c->ring)
       if (int rc = flush()) return rc;
-    batch_kind = adv;
+    batch_kind = kind;
     for (Slab &s : c->slabs) {
       if (multi && set_dev(s)) return LBM_ERR_HIP;
       float *slot1 = s.partials + (size_t)c->ring_fill * s.nb_total;
       float *slot2 = slot1 + s.nb_total;
       if (!multi) {
-        if (adv == 2) {
+        if (kind == KIND_MULTI) {
+          MultiArgs a{};
+          a.src = s.cells[src];
+          a.dst = s.cells[src ^ 1];
+          a.mask = s.mask;
+          a.partials = slot1;
+          a.plane_stride = s.plane_stride;
+          a.row_stride = s.row_stride;
+          a.partials_stride = (unsigned long long)s.nb_total;
+          a.nx = nx;
+          a.ny = s.rows;
+          a.tiles_x = s.m_tiles_x;
+          a.tiles_y = s.m_tiles_y;
+          a.T = adv;
+          a.accel_row = s.accel_own;
+          a.accel_next = last ? 0 : 1;
+          a.omega = c->p.omega;
+          a.aw1 = aw1;
+          a.aw2 = aw2;
+          hipLaunchKernelGGL(d2q9_multi, dim3(s.m_tiles_x * s.m_tiles_y), dim3(kMultiThreads), 0, s.s_main, a);
+        } else if (kind == KIND_FUSED2) {
           Step2Args a = base_args2(c, s, src, !last, s.f_main);
           a.partials1 = slot1;
           a.partials2 = slot2;
@@ -540,7 +588,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
       // interior launch: needs the previous set's edge rows
       HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
-      if (adv == 2) {
+      if (kind == KIND_FUSED2) {
         Step2Args e = base_args2(c, s, src, !last, s.f_edge);
         e.skip_chunk = 1;  // chunk table {bottom edge, (interior), top edge}
         e.partials1 = slot1 + s.f_main.units;
@@ -1036,6 +1084,11 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   }
   if (!strcmp(key, "nt_stores")) { c->nt_stores = (int)value; return LBM_OK; }
   if (!strcmp(key, "fuse")) { c->fuse = (int)value; return LBM_OK; }
+  if (!strcmp(key, "multistep")) {
+    if (value < -1 || value > kMultiMaxT) return fail(LBM_ERR_ARG, "multistep must be -1..%d", kMultiMaxT);
+    c->multistep = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "vec")) {
     // cells per thread of the single-step kernel: 4 (float4 rows) or 1
     if (value != 1 && value != 4) return fail(LBM_ERR_ARG, "vec must be 1 or 4");
@@ -1061,6 +1114,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "grid_blocks")) *value = c->slabs.empty() ? 0 : c->slabs[0].nb_main;
   else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
   else if (!strcmp(key, "fuse")) *value = fuse_effective(c);
+  else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_main.units + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "use_graph")) *value = c->use_graph;

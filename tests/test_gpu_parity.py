@@ -18,6 +18,10 @@ pytestmark = pytest.mark.gpu
 
 RTOL_CELLS = 2e-5
 RTOL_AV = 1e-4
+# explicit kernel choices (library defaults pick by grid size: LDS multi-step kernel up to ~512x512,
+# two-steps-per-launch kernel from ~1024x768, one step per launch in between and as the odd last step)
+SINGLE = {"fuse": 0, "multistep": 0}
+FUSED2 = {"fuse": 1, "multistep": 0}
 
 
 def max_rel(a, b):
@@ -77,8 +81,8 @@ def test_all_load_variants_agree_bitwise(lbm, oracle_f32, variant, nt):
     nx, ny, nsteps = 512, 24, 9
     ob, cells0 = random_case(rng, nx, ny)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
-    base, av_base = run_gpu(lbm, p, ob, cells0, nsteps, {"variant": 1, "nt_stores": 0})
-    got, av = run_gpu(lbm, p, ob, cells0, nsteps, {"variant": variant, "nt_stores": nt})
+    base, av_base = run_gpu(lbm, p, ob, cells0, nsteps, dict(SINGLE, variant=1, nt_stores=0))
+    got, av = run_gpu(lbm, p, ob, cells0, nsteps, dict(SINGLE, variant=variant, nt_stores=nt))
     assert np.array_equal(got, base) and np.array_equal(av, av_base)
     po = oracle_params(oracle_f32, p, ob)
     ref = cells0.copy()
@@ -96,8 +100,9 @@ def test_two_steps_per_launch_equals_single_steps(lbm, oracle_f32_omp, nx, ny, c
     rng = np.random.default_rng(nx + 7 * ny + nsteps)
     ob, cells0 = random_case(rng, nx, ny)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
-    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 0})
+    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     with lbm.LBM(p, ob) as sim:
+        sim.set_option("multistep", 0)
         sim.set_option("fuse", 1)
         sim.set_option("chunk_rows", chunk)
         assert sim.get_option("fuse") == 1
@@ -110,6 +115,42 @@ def test_two_steps_per_launch_equals_single_steps(lbm, oracle_f32_omp, nx, ny, c
     ref = cells0.copy()
     av_ref = oracle_f32_omp.run(po, ref, ob, nsteps)
     assert max_rel(fused, ref) < RTOL_CELLS and max_rel(av_fused, av_ref) < RTOL_AV
+
+
+@pytest.mark.parametrize("nx,ny", [(128, 128), (128, 256), (256, 256), (3, 3), (5, 4), (33, 17), (100, 70), (130, 31), (512, 48)])
+@pytest.mark.parametrize("T,nsteps", [(1, 3), (2, 7), (3, 8), (8, 8), (8, 21), (5, 16)])
+def test_lds_multistep_equals_single_steps(lbm, oracle_f32_omp, nx, ny, T, nsteps):
+    """d2q9_multi (T timesteps per launch on LDS tiles with 2T-cell redundant halos; tiles that hang over the grid
+    edge, regions that wrap around tiny grids several times, step counts that are no multiple of T) performs the same
+    per-cell arithmetic as T launches of d2q9_step: bit-identical states, av_vels equal up to summation order"""
+    rng = np.random.default_rng(nx * 31 + ny + T)
+    ob, cells0 = random_case(rng, nx, ny, blocked=0.08 if nx * ny > 30 else 0.0)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob) as sim:
+        sim.set_option("multistep", T)
+        assert sim.get_option("multistep") == T
+        sim.upload(cells0)
+        sim.run(nsteps)
+        multi, av_multi = sim.download()
+    assert np.array_equal(multi, single)
+    assert np.max(np.abs(av_multi - av_single)) <= 2e-6 * np.max(np.abs(av_single)) + 1e-12
+    po = oracle_params(oracle_f32_omp, p, ob)
+    ref = cells0.copy()
+    av_ref = oracle_f32_omp.run(po, ref, ob, nsteps)
+    assert max_rel(multi, ref) < RTOL_CELLS
+    assert np.max(np.abs(av_multi - av_ref)) <= RTOL_AV * np.max(np.abs(av_ref)) + 1e-12
+
+
+def test_default_kernel_choice_by_grid_size(lbm):
+    """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel for bandwidth-bound ones"""
+    expect = {(128, 128): (8, 0), (256, 256): (8, 0), (512, 512): (8, 0), (1024, 512): (0, 0), (1024, 1024): (0, 1),
+              (2048, 1024): (0, 1)}
+    for (nx, ny), (ms, fuse) in expect.items():
+        ob = np.zeros((ny, nx), np.int32)
+        with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
+            assert (sim.get_option("multistep"), sim.get_option("fuse") if not ms else 0) == (ms, fuse), (nx, ny)
+            sim.run(4)  # and it runs
 
 
 @pytest.mark.parametrize("nx,ny", [(3, 3), (5, 4), (30, 17), (132, 40), (256, 3), (260, 7), (1024, 5), (64, 300)])
@@ -164,7 +205,9 @@ def test_step_counts_and_repeated_runs(lbm, oracle_f32):
         parts, av_parts = sim.download()
         with pytest.raises(lbm.LBMError):
             sim.run(1)  # av_vels record is full
-    assert np.array_equal(whole, parts) and np.array_equal(av_whole, av_parts)
+    # states are bit-identical however the run is cut; av_vels only up to summation order (the cut changes
+    # which kernel / which sub-step of a multi-step launch computes a given step)
+    assert np.array_equal(whole, parts) and max_rel(av_parts, av_whole) < 2e-6
     po = oracle_params(oracle_f32, p, ob)
     ref = cells0.copy()
     av_ref = oracle_f32.run(po, ref, ob, total)
@@ -238,7 +281,7 @@ def test_row_slabs_equal_single_slab(lbm, nslabs, ny, fuse):
     ob[0, :] = 0
     ob[-1, :] = 0  # open top/bottom: the y wrap-around between the last and the first slab carries flow
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
-    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 0})
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": fuse}, devices=[0] * nslabs)
     assert np.array_equal(one, many)                 # per-cell arithmetic is identical
     assert max_rel(av_many, av_one) < 2e-6           # only the summation order of av_vels differs
@@ -262,7 +305,7 @@ def test_row_slabs_large_fused(lbm):
     nx, ny, nsteps = 2048, 512, 11
     ob, cells0 = random_case(rng, nx, ny, blocked=0.02)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
-    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 0})
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 1}, devices=[0, 0, 0, 0])
     assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
 
