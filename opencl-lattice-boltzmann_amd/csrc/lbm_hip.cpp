@@ -214,18 +214,18 @@ bool fuse_possible(const lbm_ctx *c) {
 bool fuse_effective(const lbm_ctx *c) {
   if (!fuse_possible(c)) return false;
   if (c->fuse >= 0) return c->fuse != 0;
-  // auto: measured break-even on MI355X is just below 1024x1024 (99 vs 79 GLUPS there, 42 vs 46 at 512x512:
-  // small grids have too few strip x chunk units to fill 2048 wave slots)
-  return (long)c->p.nx * c->slabs[0].rows >= 768L * 1024;
+  // auto: from 768x768 up it beats one launch per step (profiles/r01_kernel_choice.txt); smaller grids have too
+  // few strip x chunk units to fill 2048 wave slots
+  return (long)c->p.nx * c->slabs[0].rows > 540L * 1024;
 }
 
 // LDS multi-step kernel: one slab holding the whole periodic grid; worth it only while the grid is launch-bound
 int multistep_effective(const lbm_ctx *c) {
   if (c->halo_mode) return 0;
   if (c->multistep >= 0) return std::min(c->multistep, kMultiMaxT);
-  // auto: up to ~512x512 (measured: 1.6-1.8 us/step against 3.4-5.7 us for one launch per step); beyond that
-  // the tiles no longer fit one round of workgroups and the bandwidth-oriented kernels win
-  return ((long)c->p.nx * c->p.ny <= 300L * 1024) ? kMultiMaxT : 0;
+  // auto: up to 1024x512 cells (profiles/r01_kernel_choice.txt: 128x128 1.7 us/step against 3.8 with one launch
+  // per step, 1024x512 6.7 against 7.4 for the two-step kernel; from 768x768 on the two-step kernel wins)
+  return ((long)c->p.nx * c->p.ny <= 540L * 1024) ? kMultiMaxT : 0;
 }
 
 // Work decomposition of d2q9_step2 over stored rows [r0, r1): strips x chunks.  A unit's cost is
