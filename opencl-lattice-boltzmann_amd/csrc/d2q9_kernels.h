@@ -453,63 +453,87 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   const size_t ps = a.plane_stride;
   auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
 
+  // Neighbouring chunks sweep in OPPOSITE directions (even chunks upward, odd ones downward): two chunks
+  // that share a boundary then reach it at the same time — both at their start or both at their end — so
+  // the rows they both read (each chunk computes one intermediate row beyond either end) are fetched from
+  // HBM once and found in the XCD's L2 the second time.  The direction only changes which three planes
+  // travel with the older row of the register window (2,5,6 upward / 4,8,7 downward): wave-uniform selects.
+  const bool up = __builtin_amdgcn_readfirstlane((int)((chunk & 1) == 0)) != 0;
+  const int n = ye - ys;
+  const int d = up ? 1 : -1;
+  const int r0 = up ? ys - 1 : ye;  // k-th intermediate row computed: r0 + k*d, k = 0 .. n+1; rows k = 1..n are owned
+
   float sum1 = 0.f, sum2 = 0.f;
-  float low[3][4];   // planes 2,5,6 of I(row-2 relative to top)
-  float mid[6][4];   // planes 0,1,3,2,5,6 of I(row-1)
-  float top[9][4];   // I(row)
+  float trail[3][4];  // of the oldest row of the window: the planes moving in sweep direction (no shift, from west, from east)
+  float mid[6][4];    // of the middle row: planes 0,1,3 and the three that become `trail`
+  float top[9][4];    // newest intermediate row
   uint32_t m_mid, m_top;
   // two row-sets of source loads are kept in flight (ping-pong) so that HBM latency is covered by
   // both collision passes of an iteration
   RowLoads inA, inB;
-  issue_row_loads(a, wrap(ys - 1), xcol, xhalo_w, xhalo_e, lane, inA);
-  issue_row_loads(a, ys, xcol, xhalo_w, xhalo_e, lane, inB);
+  issue_row_loads(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, inA);
+  issue_row_loads(a, wrap(r0 + d), xcol, xhalo_w, xhalo_e, lane, inB);
 #pragma unroll
   for (int v = 0; v < 4; v++) {
-    low[0][v] = low[1][v] = low[2][v] = 0.f;
+    trail[0][v] = trail[1][v] = trail[2][v] = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; k++) mid[k][v] = 0.f;
   }
   m_mid = 0;
-  // one iteration: intermediate row j from `in` (then refill `in` with row j+2), output row j-1
-  auto iterate = [&](int j, RowLoads &in) {
-    // intermediate row j; rows ys-1 and ye belong to the neighbouring chunks: computed, not summed
-    const float t1 = first_step_row(a, in, wrap(j), top);
+  // one iteration: intermediate row k from `in` (then refill `in` with row k+2), output row k-1
+  auto iterate = [&](int k, RowLoads &in) {
+    const float t1 = first_step_row(a, in, wrap(r0 + k * d), top);
     m_top = in.m;
-    if (owner && j >= ys && j < ye) sum1 += t1;
-    if (j + 2 <= ye) issue_row_loads(a, wrap(j + 2), xcol, xhalo_w, xhalo_e, lane, in);
-    // step t+2 of row j-1 (needs intermediate rows j-2, j-1, j: from the third iteration on); y-shifted
-    // values come from this lane's own registers, x-shifted ones by DPP
-    if (j > ys) {
-      const int y = j - 1;
-      float g[9][4], o[9][4];
-#pragma unroll
-      for (int v = 0; v < 4; v++) { g[0][v] = mid[0][v]; g[2][v] = low[0][v]; g[4][v] = top[4][v]; }
+    if (owner && k >= 1 && k <= n) sum1 += t1;  // rows k = 0 and n+1 belong to the neighbouring chunks
+    if (k + 2 <= n + 1) issue_row_loads(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    // step t+2 of the middle row of the window (complete from the third iteration on); y-shifted values come
+    // from this lane's own registers, x-shifted ones by DPP
+    if (k >= 2) {
+      const int y = r0 + (k - 1) * d;
+      float g[9][4], o[9][4], a1[4], a2[4], b1[4], b2[4], t[4];
       shift_from_west(mid[1], 0.f, g[1]);
       shift_from_east(mid[2], 0.f, g[3]);
-      shift_from_west(low[1], 0.f, g[5]);
-      shift_from_east(low[2], 0.f, g[6]);
-      shift_from_east(top[7], 0.f, g[7]);
-      shift_from_west(top[8], 0.f, g[8]);
+      shift_from_west(trail[1], 0.f, a1);
+      shift_from_east(trail[2], 0.f, a2);
+#pragma unroll
+      for (int v = 0; v < 4; v++) t[v] = up ? top[8][v] : top[5][v];
+      shift_from_west(t, 0.f, b1);
+#pragma unroll
+      for (int v = 0; v < 4; v++) t[v] = up ? top[7][v] : top[6][v];
+      shift_from_east(t, 0.f, b2);
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const float b0 = up ? top[4][v] : top[2][v];
+        g[0][v] = mid[0][v];
+        g[2][v] = up ? trail[0][v] : b0;
+        g[4][v] = up ? b0 : trail[0][v];
+        g[5][v] = up ? a1[v] : b1[v];
+        g[8][v] = up ? b1[v] : a1[v];
+        g[6][v] = up ? a2[v] : b2[v];
+        g[7][v] = up ? b2[v] : a2[v];
+      }
       const float t2 = collide4(g, m_mid, a.omega, (y == a.accel_row) && a.accel_next, a.aw1, a.aw2, o);
       if (owner) {
         sum2 += t2;
-        float *d = a.dst + (size_t)y * a.row_stride + xcol;
+        float *dp = a.dst + (size_t)y * a.row_stride + xcol;
 #pragma unroll
-        for (int k = 0; k < 9; k++) store4<NT>(d + k * ps, o[k][0], o[k][1], o[k][2], o[k][3]);
+        for (int kk = 0; kk < 9; kk++) store4<NT>(dp + kk * ps, o[kk][0], o[kk][1], o[kk][2], o[kk][3]);
       }
     }
-    // rotate the register window one row up
+    // rotate the register window one row in sweep direction
 #pragma unroll
     for (int v = 0; v < 4; v++) {
-      low[0][v] = mid[3][v]; low[1][v] = mid[4][v]; low[2][v] = mid[5][v];
+      trail[0][v] = mid[3][v]; trail[1][v] = mid[4][v]; trail[2][v] = mid[5][v];
       mid[0][v] = top[0][v]; mid[1][v] = top[1][v]; mid[2][v] = top[3][v];
-      mid[3][v] = top[2][v]; mid[4][v] = top[5][v]; mid[5][v] = top[6][v];
+      mid[3][v] = up ? top[2][v] : top[4][v];
+      mid[4][v] = up ? top[5][v] : top[8][v];
+      mid[5][v] = up ? top[6][v] : top[7][v];
     }
     m_mid = m_top;
   };
-  for (int j = ys - 1; j <= ye; j += 2) {
-    iterate(j, inA);
-    if (j + 1 <= ye) iterate(j + 1, inB);
+  for (int k = 0; k <= n + 1; k += 2) {
+    iterate(k, inA);
+    if (k + 1 <= n + 1) iterate(k + 1, inB);
   }
   sum1 = wave_sum(sum1);
   sum2 = wave_sum(sum2);

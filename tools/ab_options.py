@@ -12,7 +12,7 @@ for (nx, ny, steps) in [(8192, 8192, 100), (4096, 4096, 400), (2048, 2048, 1000)
     ob = cavity(nx, ny)
     p = lbm_amd.make_params(nx, ny, 100000, obstacles=ob)
     with lbm_amd.LBM(p, ob) as sim:
-        configs = [("fuse", 0, 0, 0)] + [("fuse", 1, cr, cm) for cr in (6, 8, 12, 32) for cm in (2, 4) if cr <= ny and cm <= cr]
+        configs = [("fuse", 0, 0, 0)] + [("fuse", 1, cr, cm) for cr in (6, 8, 12, 16, 32) for cm in (2, 4) if cr <= ny and cm <= cr]
         for rnd in range(2):
             for (_, fuse, cr, cm) in configs:
                 sim.set_option("fuse", fuse)
