@@ -302,7 +302,9 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), cmax));
     if (multi) {
       // the two edge chunks hold the rows the neighbours need (2 each); the interior is everything else
-      s.edge_rows = std::min(std::max(2, cmax), s.rows / 2);
+      // edge chunks as short as the exchange allows (2 rows): an edge unit is one wave's serial sweep and,
+      // together with the exchange, the critical path of a launch set (profiles/r01_overlap_trace.txt)
+      s.edge_rows = 2;
       FuseGeom &e = s.f_edge;
       // edge schedule: chunk table {bottom edge, interior, top edge}; the launch skips chunk 1
       std::vector<int> tab = {s.row0, s.row0 + s.edge_rows, s.row0 + s.rows - s.edge_rows, s.row0 + s.rows};
@@ -695,7 +697,13 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   const bool multi = c->halo_mode;
   if (set_dev(s)) return LBM_ERR_HIP;
   HIP_TRY(hipStreamCreateWithFlags(&s.s_main, hipStreamNonBlocking));
-  if (multi) HIP_TRY(hipStreamCreateWithFlags(&s.s_edge, hipStreamNonBlocking));
+  if (multi) {
+    // the edge launch and the halo exchange are the critical path of a launch set (the neighbours wait for
+    // them) while the interior launch fills the machine: give the edge stream the highest priority
+    int prio_low = 0, prio_high = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    HIP_TRY(hipStreamCreateWithPriority(&s.s_edge, hipStreamNonBlocking, prio_high));
+  }
   for (int i = 0; i < 2; i++) {
     HIP_TRY(hipEventCreateWithFlags(&s.ev_main[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s.ev_edgek[i], hipEventDisableTiming));
