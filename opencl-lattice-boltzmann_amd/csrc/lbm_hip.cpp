@@ -292,8 +292,16 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
   }
   if (fuse_possible(c)) {
     const int q4 = c->p.nx / 4;
-    s.strips = div_up(q4, 62);  // lanes 0 and 63 of every wave are halo lanes
-    s.lanes_out = div_up(q4, s.strips);
+    // x decomposition: lanes 0 and 63 of a wave are halo lanes, so a strip has at most 62 output lanes — but
+    // strips must start on 64-byte boundaries (multiples of 4 lanes): with 61-lane strips (976 B) the stores of
+    // neighbouring strips split 64-B DRAM bursts and the kernel ran 9 % slower (147.8 vs 162.1 GLUPS on 8192x8192,
+    // tools/ab_lanes.py) although 60-lane strips leave more lanes idle
+    s.strips = div_up(q4, 60);
+    s.lanes_out = std::min(60, (div_up(q4, s.strips) + 3) / 4 * 4);
+    if (const char *lo = getenv("LBM_LANES_OUT")) {  // tuning: output lanes per strip (<= 62)
+      s.lanes_out = std::max(1, std::min(62, atoi(lo)));
+      s.strips = div_up(q4, s.lanes_out);
+    }
     // measured optimum (profiles/r01_fused_sweep.txt): short chunks — the rows concurrently in flight on an
     // XCD then fit the caches, which absorbs the re-read boundary rows; 6/2 from 4096x4096 up, 8/4 below
     const bool big = (long)c->p.nx * s.rows >= 8L << 20;
