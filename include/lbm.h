@@ -133,6 +133,7 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "chunk_min"    fewest rows per wave at the tapered end of the schedule (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)
  *   "nt_stores"    1 = non-temporal stores for the destination grid, 0 = plain, -1 = auto
+ *   "nt_loads"     1 = non-temporal source loads in the two-step kernel, 0 = plain, -1 = auto
  *   "use_graph"    1 = replay the step loop from a hipGraph, 0 = eager launches, -1 = auto
  *   "transport"    0 = auto, 1 = RCCL send/recv, 2 = device-to-device copies (single process only)
  */

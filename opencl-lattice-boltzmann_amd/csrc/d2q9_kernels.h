@@ -377,21 +377,31 @@ struct RowLoads {
   uint32_t m;
 };
 
+template <bool NTL>
+__device__ __forceinline__ float4 load4(const float *p) {
+  if (NTL) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const float4 *>(p);
+}
+
+template <bool NTL>
 __device__ __forceinline__ void issue_row_loads(const Step2Args &a, int r, int xcol, int xhalo_w, int xhalo_e, int lane,
                                                 RowLoads &in) {
   const size_t ps = a.plane_stride, rs = a.row_stride;
   const int r_s = (r == 0) ? a.ny - 1 : r - 1;
   const int r_n = (r == a.ny - 1) ? 0 : r + 1;
   const float *Rc = a.src + (size_t)r * rs, *Rs = a.src + (size_t)r_s * rs, *Rn = a.src + (size_t)r_n * rs;
-  in.c[0] = *reinterpret_cast<const float4 *>(Rc + xcol);
-  in.c[1] = *reinterpret_cast<const float4 *>(Rc + 1 * ps + xcol);
-  in.c[3] = *reinterpret_cast<const float4 *>(Rc + 3 * ps + xcol);
-  in.c[2] = *reinterpret_cast<const float4 *>(Rs + 2 * ps + xcol);
-  in.c[5] = *reinterpret_cast<const float4 *>(Rs + 5 * ps + xcol);
-  in.c[6] = *reinterpret_cast<const float4 *>(Rs + 6 * ps + xcol);
-  in.c[4] = *reinterpret_cast<const float4 *>(Rn + 4 * ps + xcol);
-  in.c[7] = *reinterpret_cast<const float4 *>(Rn + 7 * ps + xcol);
-  in.c[8] = *reinterpret_cast<const float4 *>(Rn + 8 * ps + xcol);
+  in.c[0] = load4<NTL>(Rc + xcol);
+  in.c[1] = load4<NTL>(Rc + 1 * ps + xcol);
+  in.c[3] = load4<NTL>(Rc + 3 * ps + xcol);
+  in.c[2] = load4<NTL>(Rs + 2 * ps + xcol);
+  in.c[5] = load4<NTL>(Rs + 5 * ps + xcol);
+  in.c[6] = load4<NTL>(Rs + 6 * ps + xcol);
+  in.c[4] = load4<NTL>(Rn + 4 * ps + xcol);
+  in.c[7] = load4<NTL>(Rn + 7 * ps + xcol);
+  in.c[8] = load4<NTL>(Rn + 8 * ps + xcol);
   in.m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)r * a.nx + xcol);
   in.h0 = in.h1 = in.h2 = 0.f;
   if (lane == 0 || lane == 63) {
@@ -426,7 +436,7 @@ __device__ __forceinline__ float first_step_row(const Step2Args &a, const RowLoa
   return collide4(g, in.m, a.omega, r == a.accel_row, a.aw1, a.aw2, I);
 }
 
-template <bool NT>
+template <bool NT, bool NTL = false>
 __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   const int lane = threadIdx.x;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, MI355X_MICROARCH.md), so
@@ -471,8 +481,8 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   // two row-sets of source loads are kept in flight (ping-pong) so that HBM latency is covered by
   // both collision passes of an iteration
   RowLoads inA, inB;
-  issue_row_loads(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, inA);
-  issue_row_loads(a, wrap(r0 + d), xcol, xhalo_w, xhalo_e, lane, inB);
+  issue_row_loads<NTL>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, inA);
+  issue_row_loads<NTL>(a, wrap(r0 + d), xcol, xhalo_w, xhalo_e, lane, inB);
 #pragma unroll
   for (int v = 0; v < 4; v++) {
     trail[0][v] = trail[1][v] = trail[2][v] = 0.f;
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
     const float t1 = first_step_row(a, in, wrap(r0 + k * d), top);
     m_top = in.m;
     if (owner && k >= 1 && k <= n) sum1 += t1;  // rows k = 0 and n+1 belong to the neighbouring chunks
-    if (k + 2 <= n + 1) issue_row_loads(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    if (k + 2 <= n + 1) issue_row_loads<NTL>(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
     // step t+2 of the middle row of the window (complete from the third iteration on); y-shifted values come
     // from this lane's own registers, x-shifted ones by DPP
     if (k >= 2) {
