@@ -427,11 +427,14 @@ Step2Args base_args2(const lbm_ctx *c, const Slab &s, int src, bool accel_next, 
 }
 
 void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t st) {
-  // grids beyond the Infinity Cache: every source value is read once (boundary rows twice, by a neighbouring
-  // chunk at the same time) — non-temporal loads keep them from displacing each other: +3 % on 8192x8192, +7 % on 4096x4096
-  const bool ntl = c->nt_loads >= 0 ? c->nt_loads != 0 : nt_effective(c);
+  // Non-temporal loads AND stores by default at every size this kernel is used for: each source value is
+  // read once (boundary rows twice, by the neighbouring chunk at the same time) and each result is not read
+  // again before the next launch.  Same-box A/B (tools/ab_head.py): 8192x8192 +3.5 %, 4096x4096 +6.6 %,
+  // 2048x2048 +6.9 %, 1024x1024 +12.7 % over plain loads (the single-step kernel keeps its size rule).
+  const bool nts = c->nt_stores >= 0 ? c->nt_stores != 0 : true;
+  const bool ntl = c->nt_loads >= 0 ? c->nt_loads != 0 : nts;
   if (ntl) hipLaunchKernelGGL((d2q9_step2<true, true>), dim3(units), dim3(64), 0, st, a);
-  else if (nt_effective(c)) hipLaunchKernelGGL((d2q9_step2<true>), dim3(units), dim3(64), 0, st, a);
+  else if (nts) hipLaunchKernelGGL((d2q9_step2<true>), dim3(units), dim3(64), 0, st, a);
   else hipLaunchKernelGGL((d2q9_step2<false>), dim3(units), dim3(64), 0, st, a);
 }
 
