@@ -57,7 +57,7 @@ typedef struct lbm_ctx lbm_ctx; /* opaque; replaces t_ocl (d2q9-bgk.c:97-119) */
  *   ndev       number of row slabs; the grid is row-partitioned over dev_ids[0..ndev).  ndev <= 1
  *              with dev_ids == NULL uses the current HIP device.  A device may be listed more than
  *              once (several slabs on one GPU): halos then move by device-to-device copies instead
- *              of RCCL.  Requires ny >= 2*ndev... rows per slab >= 2.
+ *              of RCCL.  Every slab needs at least 4 rows.
  */
 int lbm_create(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles, int ndev, const int *dev_ids);
 
@@ -134,8 +134,8 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)
  *   "nt_stores"    1 = non-temporal stores for the destination grid, 0 = plain, -1 = auto
  *   "nt_loads"     1 = non-temporal source loads in the two-step kernel, 0 = plain, -1 = auto
- *   "use_graph"    1 = replay the step loop from a hipGraph, 0 = eager launches, -1 = auto
- *   "transport"    0 = auto, 1 = RCCL send/recv, 2 = device-to-device copies (single process only)
+ * Read-only through lbm_get_option: "transport" (1 = RCCL send/recv, 2 = device-to-device copies; chosen at
+ * creation, environment LBM_TRANSPORT=rccl|copy overrides for single-process contexts), "nslabs", "fuse_units".
  */
 int lbm_set_option(lbm_ctx *ctx, const char *key, long value);
 int lbm_get_option(const lbm_ctx *ctx, const char *key, long *value);

@@ -154,14 +154,12 @@ struct lbm_ctx {
   int steps_done = 0;
   int ring_fill = 0;        // buffered steps not yet reduced
   int ring = kRingMax;      // slots in the partial-sum ring (smaller for grids with many workgroups)
-  int transport = TRANSPORT_AUTO;
   int transport_eff = TRANSPORT_COPY;
   // options
   int variant = 0;
   int grid_blocks = 0;
   int nt_stores = -1;
   int nt_loads = -1;        // non-temporal source loads in d2q9_step2: -1 auto (with nt stores), 0 off, 1 on
-  int use_graph = -1;
   int fuse = -1;            // two timesteps per launch (d2q9_step2): -1 auto, 0 off, 1 on
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
@@ -1128,8 +1126,6 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     (key[6] == 'r' ? c->chunk_rows : c->chunk_min) = (int)value;
     return rebuild_geometry(c);
   }
-  if (!strcmp(key, "use_graph")) { c->use_graph = (int)value; return LBM_OK; }
-  if (!strcmp(key, "transport")) { c->transport = (int)value; return LBM_OK; }
   return fail(LBM_ERR_ARG, "unknown option '%s'", key);
 }
 
@@ -1142,7 +1138,6 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_main.units + c->slabs[0].f_edge.units;
-  else if (!strcmp(key, "use_graph")) *value = c->use_graph;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;
   else return fail(LBM_ERR_ARG, "unknown option '%s'", key);
