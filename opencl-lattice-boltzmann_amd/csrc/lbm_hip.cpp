@@ -244,9 +244,16 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     split_rows(rows, g.nbands, b, &y0, &n);
     std::vector<int> sizes;
     int rem = n;
+    // a grid small enough to be done in ONE round of units (all of them resident at once) gets equal chunks
+    // that just fill the wave slots: every extra unit costs two redundant rows, and a second, partly filled
+    // round costs more than it balances (1024x1024: 3-row chunks = 1720 units: 10.2 us/step; 2-row chunks =
+    // 2560 units: 12.1; 4-row chunks = 1280 units: 11.6 — tools/ab_1024.py)
+    const int one_round = (int)std::ceil(n / std::floor(slots));
+    const bool single_round = one_round <= cmax;
     while (rem > 0) {
-      int sz = (int)std::ceil(rem / (2.0 * slots));
-      sz = std::min(std::max(cmin, std::min(cmax, sz)), rem);
+      int sz = single_round ? std::max(2, one_round) : (int)std::ceil(rem / (2.0 * slots));
+      if (!single_round) sz = std::max(cmin, std::min(cmax, sz));
+      sz = std::min(sz, rem);
       sizes.push_back(sz);
       rem -= sz;
     }
