@@ -17,25 +17,25 @@ import sys
 import numpy as np
 
 
-class InputParser(argparse.ArgumentParser):
-    """Argument set of the reference checker (check/check.py:17-57)."""
+# (flag, help text) of the four file arguments, all required, one value each (check/check.py:32-57)
+FILE_ARGUMENTS = (
+    ("--ref-av-vels-file", "reference av_vels results file"),
+    ("--ref-final-state-file", "reference final_state results file"),
+    ("--av-vels-file", "calculated av_vels results file"),
+    ("--final-state-file", "calculated final_state results file"),
+)
 
-    def __init__(self):
-        super().__init__(
-            description="Testing script for HPC LBM coursework",
-            fromfile_prefix_chars="@",
-            formatter_class=argparse.ArgumentDefaultsHelpFormatter,
-        )
-        self.add_argument("--tolerance", nargs=1, default=[1], type=float,
-                          help="""Percentage tolerance to match against reference results""", action="store")
-        self.add_argument("--ref-av-vels-file", nargs=1, required=True,
-                          help="""reference av_vels results file""", action="store")
-        self.add_argument("--ref-final-state-file", nargs=1, required=True,
-                          help="""reference final_state results file""", action="store")
-        self.add_argument("--av-vels-file", nargs=1, required=True,
-                          help="""calculated av_vels results file""", action="store")
-        self.add_argument("--final-state-file", nargs=1, required=True,
-                          help="""calculated final_state results file""", action="store")
+
+def make_parser():
+    """Argument set of the reference checker (check/check.py:17-57): same flags, defaults and help texts;
+    arguments may also come from a file given as @file."""
+    parser = argparse.ArgumentParser(description="Testing script for HPC LBM coursework", fromfile_prefix_chars="@",
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("--tolerance", nargs=1, type=float, default=[1],
+                        help="Percentage tolerance to match against reference results")
+    for flag, text in FILE_ARGUMENTS:
+        parser.add_argument(flag, nargs=1, required=True, help=text)
+    return parser
 
 
 def load_dat_files(av_vels_filename, final_state_filename):
@@ -121,7 +121,7 @@ def run_check(ref_av_vels_file, ref_final_state_file, av_vels_file, final_state_
 
 
 def main(argv=None):
-    args = InputParser().parse_args(argv)
+    args = make_parser().parse_args(argv)
     code, _, _ = run_check(args.ref_av_vels_file[0], args.ref_final_state_file[0],
                            args.av_vels_file[0], args.final_state_file[0], args.tolerance[0])
     return code
