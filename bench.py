@@ -77,6 +77,35 @@ def cpu_baseline(nx, ny, obstacles, accel, budget_s=15.0):
                       "(oracle/d2q9_oracle.c, gcc -O3 -march=native, 1 of %d host cores)" % (n, nx, ny, os.cpu_count())}
 
 
+# ---- torch.distributed plumbing (also exercised with the gloo backend on CPU: tests/test_multirank_gloo.py) ----
+
+def init_dist(backend, rank, world, device=None):
+    """One process per GPU: MASTER_ADDR/MASTER_PORT come from the launcher (torch.distributed.run)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def share_comm_id(dist, rank, blob, nbytes, device):
+    """Rank 0 made the RCCL unique id (lbm_comm_get_id); every rank gets the same bytes."""
+    import torch
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    if rank == 0:
+        assert len(blob) == nbytes
+        buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+    dist.broadcast(buf, src=0)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def max_over_ranks(dist, values, device):
+    import torch
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,11 +135,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dist = init_dist("nccl", rank, world, torch.device("cuda", local_rank)) if world > 1 else None
 
     nx = args.nx
     ny = args.ny * (world if args.scaling == "weak" else 1)
@@ -119,12 +144,9 @@ def main():
     params = lbm_amd.make_params(nx, ny, total_steps, 10, 0.1, args.accel, 1.85, obstacles)
 
     if world > 1:
-        idbuf = torch.zeros(lbm_amd.load_library().lbm_comm_id_size(), dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idbuf.copy_(torch.frombuffer(bytearray(lbm_amd.comm_id()), dtype=torch.uint8))
-        dist.broadcast(idbuf, src=0)
-        sim = lbm_amd.LBM(params, obstacles, rank=rank, nranks=world, device=local_rank,
-                          comm=bytes(idbuf.cpu().numpy().tobytes()))
+        cid = share_comm_id(dist, rank, lbm_amd.comm_id() if rank == 0 else None,
+                            lbm_amd.load_library().lbm_comm_id_size(), torch.device("cuda", local_rank))
+        sim = lbm_amd.LBM(params, obstacles, rank=rank, nranks=world, device=local_rank, comm=cid)
     else:
         sim = lbm_amd.LBM(params, obstacles)
     if args.fuse >= 0:
@@ -146,9 +168,7 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall, loop_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, loop_ms = float(t[0]), float(t[1])
+        wall, loop_ms = max_over_ranks(dist, [wall, loop_ms], torch.device("cuda", local_rank))
 
     # sanity on the result of the timed run: finite, positive average velocity on every rank
     _, av = sim.download(cells=False)

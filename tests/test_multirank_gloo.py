@@ -103,3 +103,27 @@ def test_slab_geometry_helpers():
         assert y0 + lbm_amd.accel_row_local(ny, y0, rows) == ny - 2
     assert lbm_amd.ring_neighbours(8, 0) == (7, 1) and lbm_amd.ring_neighbours(8, 7) == (6, 0)
     assert lbm_amd.ring_neighbours(1, 0) == (0, 0)
+
+
+def _bench_plumbing(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import bench
+    dist = bench.init_dist("gloo", rank, world)
+    blob = bytes(range(128)) if rank == 0 else None
+    got = bench.share_comm_id(dist, rank, blob, 128, torch.device("cpu"))
+    mx = bench.max_over_ranks(dist, [1.0 + rank, 10.0 - rank], torch.device("cpu"))
+    dist.barrier()
+    with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+        f.write("%s %s" % (got == bytes(range(128)), mx))
+    dist.destroy_process_group()
+
+
+def test_bench_distributed_plumbing(tmp_path):
+    """bench.py's rank plumbing (process group, RCCL-id broadcast, max-over-ranks timing) with gloo, 2 ranks"""
+    import torch.multiprocessing as mp
+    mp.spawn(_bench_plumbing, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / ("r%d.txt" % r)).read() == "True [2.0, 10.0]"
