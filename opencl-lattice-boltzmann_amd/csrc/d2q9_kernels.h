@@ -571,10 +571,14 @@ struct MultiArgs {
   const uint8_t *mask;
   float *partials;          // [T][partials_stride]: per-tile sums of |j|/rho for each of the T steps
   unsigned long long plane_stride, row_stride, partials_stride;
-  int nx, ny;
-  int tiles_x, tiles_y;
-  int T;                    // steps in this launch
-  int accel_row;            // ny-2
+  int nx;
+  int rows;                 // owned rows (the whole grid with one slab)
+  int ext_rows;             // rows stored (owned + halo rows below and above)
+  int row_off;              // stored row of owned row 0; 0 = no halo rows: y wraps periodically inside the kernel
+  int tiles_x;
+  int ty_begin, ty_split, ty_begin2;  // tile row of workgroup-row t: t < ty_split ? ty_begin + t : ty_begin2 + (t - ty_split)
+  int T;                    // steps in this launch (<= row_off when there are halo rows)
+  int gy_off, ny_global;    // stored row r holds global row (gy_off + r) mod ny_global; accelerate_flow acts on ny_global-2
   int accel_next;           // apply the following step's accelerate_flow to the final state
   float omega, aw1, aw2;
 };
@@ -586,22 +590,35 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
   const int tid = threadIdx.x;
   const int T = a.T;
   const int RX = kMultiTX + 2 * T, RY = kMultiTY + 2 * T;
-  const int tile_y = blockIdx.x / a.tiles_x, tile_x = blockIdx.x - tile_y * a.tiles_x;
-  const int gx0 = tile_x * kMultiTX - T, gy0 = tile_y * kMultiTY - T;  // global coordinates of region cell (0,0)
+  const int trow = blockIdx.x / a.tiles_x, tile_x = blockIdx.x - trow * a.tiles_x;
+  const int tile_y = trow < a.ty_split ? a.ty_begin + trow : a.ty_begin2 + (trow - a.ty_split);
+  const int gx0 = tile_x * kMultiTX - T, oy0 = tile_y * kMultiTY - T;  // region cell (0,0): column, owned-row index
+  const bool periodic = (a.row_off == 0);
   const size_t ps = a.plane_stride;
+  // stored row of region row ry: periodic wrap with one slab (kernels.cl:91-93), else the slab's halo rows
+  auto stored_row = [&](int ry) {
+    int r = oy0 + ry;
+    if (periodic) {
+      r %= a.rows;
+      if (r < 0) r += a.rows;
+      return r;
+    }
+    r += a.row_off;
+    return r < 0 ? 0 : (r >= a.ext_rows ? a.ext_rows - 1 : r);  // clamped rows only feed cells that are never stored
+  };
 
-  // region -> LDS (periodic wrap in both directions, kernels.cl:91-102)
+  // region -> LDS (periodic wrap in x, kernels.cl:99-102)
   {
     const float inv = 1.0f / (float)RX;
     for (int i = tid; i < RX * RY; i += kMultiThreads) {
       const int ry = (int)(((float)i + 0.5f) * inv), rx = i - ry * RX;
-      int gx = (gx0 + rx) % a.nx, gy = (gy0 + ry) % a.ny;
+      int gx = (gx0 + rx) % a.nx;
       if (gx < 0) gx += a.nx;
-      if (gy < 0) gy += a.ny;
-      const float *p = a.src + (size_t)gy * a.row_stride + gx;
+      const int sr = stored_row(ry);
+      const float *p = a.src + (size_t)sr * a.row_stride + gx;
 #pragma unroll
       for (int k = 0; k < 9; k++) lds[0][k][ry * kMultiRX + rx] = p[k * ps];
-      lmask[ry * kMultiRX + rx] = a.mask[(size_t)gy * a.nx + gx];
+      lmask[ry * kMultiRX + rx] = a.mask[(size_t)sr * a.nx + gx];
     }
   }
   __syncthreads();
@@ -628,15 +645,18 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
       g[8] = lds[in][8][c + kMultiRX - 1];
       const bool obst = lmask[c] != 0;
       const float t = collide_cell(g, obst, a.omega, o);
-      int gy = (gy0 + ry) % a.ny;
-      if (gy < 0) gy += a.ny;
-      if (gy == a.accel_row && accel_step) accelerate_cell(o, obst, a.aw1, a.aw2);
+      if (accel_step) {
+        // by global row: with halo rows a slab may store a copy of row ny-2 besides (or instead of) its own
+        int gy = (a.gy_off + stored_row(ry)) % a.ny_global;
+        if (gy < 0) gy += a.ny_global;
+        if (gy == a.ny_global - 2) accelerate_cell(o, obst, a.aw1, a.aw2);
+      }
 #pragma unroll
       for (int k = 0; k < 9; k++) lds[out][k][c] = o[k];
       // only the tile's own cells count (and, for tiles hanging over the grid edge, only real cells)
       const int ox = rx - T, oy = ry - T;
       if (ox >= 0 && ox < kMultiTX && oy >= 0 && oy < kMultiTY && tile_x * kMultiTX + ox < a.nx &&
-          tile_y * kMultiTY + oy < a.ny)
+          tile_y * kMultiTY + oy < a.rows)
         sum += t;
     }
     sum = wave_sum(sum);
@@ -649,10 +669,10 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
     const int fin = T & 1;
     for (int i = tid; i < kMultiTX * kMultiTY; i += kMultiThreads) {
       const int oy = i / kMultiTX, ox = i - oy * kMultiTX;
-      const int gx = tile_x * kMultiTX + ox, gy = tile_y * kMultiTY + oy;
-      if (gx < a.nx && gy < a.ny) {
+      const int gx = tile_x * kMultiTX + ox, orow = tile_y * kMultiTY + oy;
+      if (gx < a.nx && orow < a.rows) {
         const int c = (oy + T) * kMultiRX + ox + T;
-        float *d = a.dst + (size_t)gy * a.row_stride + gx;
+        float *d = a.dst + (size_t)(a.row_off + orow) * a.row_stride + gx;
 #pragma unroll
         for (int k = 0; k < 9; k++) d[k * ps] = lds[fin][k][c];
       }

@@ -112,10 +112,10 @@ struct Slab {
   int dev = 0;
   int index = 0;          // position in the global ring of slabs
   int y0 = 0, rows = 0;   // global first row, rows owned
-  int row0 = 0;           // halo rows stored below (and above) the owned rows: 0 (one slab) or 2
+  int row0 = 0;           // halo rows stored below (and above) the owned rows: 0 (one slab), else the halo depth (2 or 8)
   int ext_rows = 0;       // rows stored = rows + 2*row0
   int accel_own = -1;     // stored-row index of global row ny-2 if this slab owns it, else -1
-  int accel_ext = -1;     // same, also when the row is one of the halo-adjacent rows row0-1 / row0+rows
+  int accel_ext = -1;     // same, also when the row is one of the stored halo rows
   size_t plane_stride = 0;  // floats between the 9 plane-rows of a grid row (padded row length)
   size_t row_stride = 0;    // floats between grid rows = 9*plane_stride (+ pad)
   float *cells[2] = {nullptr, nullptr};  // [ext_rows][9][plane_stride]
@@ -125,7 +125,7 @@ struct Slab {
   int nb_total = 0;              // slot stride of the ring
   int strips = 0, lanes_out = 0;  // x decomposition of d2q9_step2
   FuseGeom f_main, f_edge;        // whole slab (one slab) or interior chunks; the two edge chunks
-  int edge_rows = 0;              // rows per edge chunk in slab mode
+  int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
   double *av_sum = nullptr;   // [capacity] per-step sum of |j|/rho over this slab's fluid cells
   hipStream_t s_main = nullptr, s_edge = nullptr;
@@ -149,6 +149,7 @@ struct lbm_ctx {
   int nslabs_global = 1;    // slabs in the ring (== slabs.size() unless rank mode)
   bool rank_mode = false;
   bool halo_mode = false;   // slabs carry halo rows and exchange them (more than one slab, or forced for tests)
+  int halo_depth = 2;       // rows exchanged per side and launch set: 2 (two-step kernel) or 8 (LDS multi-step kernel, small slabs)
   int rank = 0;
   int cur = 0;              // index of the grid holding the current state
   int steps_done = 0;
@@ -220,11 +221,13 @@ bool fuse_effective(const lbm_ctx *c) {
 
 // LDS multi-step kernel: one slab holding the whole periodic grid; worth it only while the grid is launch-bound
 int multistep_effective(const lbm_ctx *c) {
-  if (c->halo_mode) return 0;
-  if (c->multistep >= 0) return std::min(c->multistep, kMultiMaxT);
+  // with halo rows a launch can advance at most as many steps as the halos are deep
+  const int cap = c->halo_mode ? std::min(kMultiMaxT, c->halo_depth) : kMultiMaxT;
+  if (c->halo_mode && c->halo_depth < kMultiMaxT && c->multistep < 0) return 0;  // big slabs: two-step kernel
+  if (c->multistep >= 0) return std::min(c->multistep, cap);
   // auto: up to 1024x512 cells (profiles/r01_kernel_choice.txt: 128x128 1.7 us/step against 3.8 with one launch
   // per step, 1024x512 6.7 against 7.4 for the two-step kernel; from 768x768 on the two-step kernel wins)
-  return ((long)c->p.nx * c->p.ny <= 540L * 1024) ? kMultiMaxT : 0;
+  return ((long)c->p.nx * c->slabs[0].rows <= 540L * 1024) ? cap : 0;
 }
 
 // Work decomposition of d2q9_step2 over stored rows [r0, r1): strips x chunks.  A unit's cost is
@@ -282,20 +285,20 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
 // All launch geometry of a slab (single-step workgroup counts, fused schedules, ring slot stride).
 int slab_geometry(const lbm_ctx *c, Slab &s) {
   const bool multi = c->halo_mode;
+  // slab mode: the edge launch computes the `halo_depth` rows at each slab edge (what the neighbours receive),
+  // the interior launch the rest
+  s.edge_rows = multi ? std::min(c->halo_depth, s.rows / 2) : 0;
   if (multi) {
-    // single-step kernel in slab mode: 2 bottom + 2 top rows first (what the neighbours receive), then the rest
-    s.nb_edge = step_blocks(c, 4);
-    s.nb_main = step_blocks(c, std::max(1, s.rows - 4));
+    s.nb_edge = step_blocks(c, 2 * s.edge_rows);
+    s.nb_main = step_blocks(c, std::max(1, s.rows - 2 * s.edge_rows));
   } else {
     s.nb_main = step_blocks(c, s.rows);
     s.nb_edge = 0;
   }
   s.nb_total = s.nb_main + s.nb_edge;
-  if (!multi) {
-    s.m_tiles_x = div_up(c->p.nx, kMultiTX);
-    s.m_tiles_y = div_up(s.rows, kMultiTY);
-    if ((long)s.m_tiles_x * s.m_tiles_y <= 65536) s.nb_total = std::max(s.nb_total, s.m_tiles_x * s.m_tiles_y);
-  }
+  s.m_tiles_x = div_up(c->p.nx, kMultiTX);
+  s.m_tiles_y = div_up(s.rows, kMultiTY);
+  if ((long)s.m_tiles_x * s.m_tiles_y <= 65536) s.nb_total = std::max(s.nb_total, s.m_tiles_x * s.m_tiles_y);
   if (fuse_possible(c)) {
     const int q4 = c->p.nx / 4;
     // x decomposition: lanes 0 and 63 of a wave are halo lanes, so a strip has at most 62 output lanes — but
@@ -316,9 +319,8 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), cmax));
     if (multi) {
       // the two edge chunks hold the rows the neighbours need (2 each); the interior is everything else
-      // edge chunks as short as the exchange allows (2 rows): an edge unit is one wave's serial sweep and,
-      // together with the exchange, the critical path of a launch set (profiles/r01_overlap_trace.txt)
-      s.edge_rows = 2;
+      // (edge chunks are as short as the exchange allows — 2 rows when the halo depth is 2: an edge unit is one
+      // wave's serial sweep and, with the exchange, the critical path of a launch set, profiles/r01_overlap_trace.txt)
       FuseGeom &e = s.f_edge;
       // edge schedule: chunk table {bottom edge, interior, top edge}; the launch skips chunk 1
       std::vector<int> tab = {s.row0, s.row0 + s.edge_rows, s.row0 + s.rows - s.edge_rows, s.row0 + s.rows};
@@ -431,6 +433,29 @@ Step2Args base_args2(const lbm_ctx *c, const Slab &s, int src, bool accel_next, 
   return a;
 }
 
+MultiArgs base_args_multi(const lbm_ctx *c, const Slab &s, int src, int T, bool accel_next) {
+  MultiArgs a{};
+  a.src = s.cells[src];
+  a.dst = s.cells[src ^ 1];
+  a.mask = s.mask;
+  a.plane_stride = s.plane_stride;
+  a.row_stride = s.row_stride;
+  a.partials_stride = (unsigned long long)s.nb_total;
+  a.nx = c->p.nx;
+  a.rows = s.rows;
+  a.ext_rows = s.ext_rows;
+  a.row_off = s.row0;
+  a.tiles_x = s.m_tiles_x;
+  a.T = T;
+  a.gy_off = s.y0 - s.row0;
+  a.ny_global = c->p.ny;
+  a.accel_next = accel_next ? 1 : 0;
+  a.omega = c->p.omega;
+  a.aw1 = c->p.density * c->p.accel / 9.0f;
+  a.aw2 = c->p.density * c->p.accel / 36.0f;
+  return a;
+}
+
 void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t st) {
   // Non-temporal loads AND stores by default at every size this kernel is used for: each source value is
   // read once (boundary rows twice, by the neighbouring chunk at the same time) and each result is not read
@@ -443,17 +468,17 @@ void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t s
   else hipLaunchKernelGGL((d2q9_step2<false>), dim3(units), dim3(64), 0, st, a);
 }
 
-// Slab mode: move the two bottom and the two top owned rows of grid `buf` into the ring neighbours'
-// halo rows of their grid `buf`.  Each pair of rows is one contiguous block of 2*row_stride floats.
+// Slab mode: move the `halo_depth` bottom and top owned rows of grid `buf` into the ring neighbours' halo
+// rows of their grid `buf`.  Each group of rows is one contiguous block of halo_depth*row_stride floats.
 int exchange_halos(lbm_ctx *c, int buf, int evq) {
   const int P = c->nslabs_global;
   if (c->transport_eff == TRANSPORT_RCCL) {
     NCCL_TRY(g_rccl.GroupStart());
     for (Slab &s : c->slabs) {
-      const size_t count = 2 * s.row_stride;
+      const size_t count = (size_t)s.row0 * s.row_stride;
       const int north = (s.index + 1) % P, south = (s.index + P - 1) % P;
       float *g = s.cells[buf];
-      NCCL_TRY(g_rccl.Send(g + (size_t)(s.row0 + s.rows - 2) * s.row_stride, count, ncclFloat, north, s.comm, s.s_edge));
+      NCCL_TRY(g_rccl.Send(g + (size_t)s.rows * s.row_stride, count, ncclFloat, north, s.comm, s.s_edge));
       NCCL_TRY(g_rccl.Send(g + (size_t)s.row0 * s.row_stride, count, ncclFloat, south, s.comm, s.s_edge));
       NCCL_TRY(g_rccl.Recv(g, count, ncclFloat, south, s.comm, s.s_edge));
       NCCL_TRY(g_rccl.Recv(g + (size_t)(s.row0 + s.rows) * s.row_stride, count, ncclFloat, north, s.comm, s.s_edge));
@@ -463,12 +488,12 @@ int exchange_halos(lbm_ctx *c, int buf, int evq) {
     // one process: each slab pulls from its neighbours once their edge launches are done
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
-      const size_t bytes = 2 * s.row_stride * sizeof(float);
+      const size_t bytes = (size_t)s.row0 * s.row_stride * sizeof(float);
       Slab &north = c->slabs[(s.index + 1) % P];
       Slab &south = c->slabs[(s.index + P - 1) % P];
       HIP_TRY(hipStreamWaitEvent(s.s_edge, south.ev_edgek[evq], 0));
       HIP_TRY(hipStreamWaitEvent(s.s_edge, north.ev_edgek[evq], 0));
-      HIP_TRY(hipMemcpyAsync(s.cells[buf], south.cells[buf] + (size_t)(south.row0 + south.rows - 2) * south.row_stride, bytes,
+      HIP_TRY(hipMemcpyAsync(s.cells[buf], south.cells[buf] + (size_t)south.rows * south.row_stride, bytes,
                              hipMemcpyDeviceToDevice, s.s_edge));
       HIP_TRY(hipMemcpyAsync(s.cells[buf] + (size_t)(s.row0 + s.rows) * s.row_stride,
                              north.cells[buf] + (size_t)north.row0 * north.row_stride, bytes, hipMemcpyDeviceToDevice, s.s_edge));
@@ -555,7 +580,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     const int src = c->cur;
     // timesteps advanced by this launch set, and with which kernel
     int kind = KIND_SINGLE, adv = 1;
-    if (multi_T > 0 && !multi && c->slabs[0].m_tiles_x * (long)c->slabs[0].m_tiles_y <= 65536) {
+    if (multi_T > 0 && c->slabs[0].m_tiles_x * (long)c->slabs[0].m_tiles_y <= 65536) {
       kind = KIND_MULTI;
       adv = std::min(multi_T, nsteps - i);
     } else if (fuse && nsteps - i >= 2) {
@@ -573,24 +598,9 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       float *slot2 = slot1 + s.nb_total;
       if (!multi) {
         if (kind == KIND_MULTI) {
-          MultiArgs a{};
-          a.src = s.cells[src];
-          a.dst = s.cells[src ^ 1];
-          a.mask = s.mask;
+          MultiArgs a = base_args_multi(c, s, src, adv, !last);
           a.partials = slot1;
-          a.plane_stride = s.plane_stride;
-          a.row_stride = s.row_stride;
-          a.partials_stride = (unsigned long long)s.nb_total;
-          a.nx = nx;
-          a.ny = s.rows;
-          a.tiles_x = s.m_tiles_x;
-          a.tiles_y = s.m_tiles_y;
-          a.T = adv;
-          a.accel_row = s.accel_own;
-          a.accel_next = last ? 0 : 1;
-          a.omega = c->p.omega;
-          a.aw1 = aw1;
-          a.aw2 = aw2;
+          a.ty_begin = 0; a.ty_split = s.m_tiles_y; a.ty_begin2 = 0;
           hipLaunchKernelGGL(d2q9_multi, dim3(s.m_tiles_x * s.m_tiles_y), dim3(kMultiThreads), 0, s.s_main, a);
         } else if (kind == KIND_FUSED2) {
           Step2Args a = base_args2(c, s, src, !last, s.f_main);
@@ -611,7 +621,25 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
       // interior launch: needs the previous set's edge rows
       HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
-      if (kind == KIND_FUSED2) {
+      if (kind == KIND_MULTI) {
+        // edge = the tile rows that hold the halo_depth bottom and top rows (what the neighbours receive):
+        // tile row 0 and the tile rows from t_top up; interior = tile rows 1 .. t_top-1
+        const int m = s.m_tiles_y;
+        const int t_top = std::max(1, std::min(m, (s.rows - s.edge_rows) / kMultiTY));
+        const int edge_trows = 1 + (m - t_top), int_trows = t_top - 1;
+        MultiArgs e = base_args_multi(c, s, src, adv, !last);
+        e.partials = slot1 + (size_t)int_trows * s.m_tiles_x;
+        e.ty_begin = 0; e.ty_split = 1; e.ty_begin2 = t_top;
+        hipLaunchKernelGGL(d2q9_multi, dim3(s.m_tiles_x * edge_trows), dim3(kMultiThreads), 0, s.s_edge, e);
+        HIP_TRY(hipGetLastError());
+        if (int_trows > 0) {
+          MultiArgs mm = base_args_multi(c, s, src, adv, !last);
+          mm.partials = slot1;
+          mm.ty_begin = 1; mm.ty_split = int_trows; mm.ty_begin2 = 0;
+          hipLaunchKernelGGL(d2q9_multi, dim3(s.m_tiles_x * int_trows), dim3(kMultiThreads), 0, s.s_main, mm);
+          HIP_TRY(hipGetLastError());
+        }
+      } else if (kind == KIND_FUSED2) {
         Step2Args e = base_args2(c, s, src, !last, s.f_edge);
         e.skip_chunk = 1;  // chunk table {bottom edge, (interior), top edge}
         e.partials1 = slot1 + s.f_main.units;
@@ -627,13 +655,13 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
         }
       } else {
         StepArgs e = base_args(c, s, src, !last);
-        e.y_begin = s.row0; e.y_count = 4; e.y_split = 2; e.y_begin2 = s.row0 + s.rows - 2;
+        e.y_begin = s.row0; e.y_count = 2 * s.edge_rows; e.y_split = s.edge_rows; e.y_begin2 = s.row0 + s.rows - s.edge_rows;
         e.partials = slot1 + s.nb_main;
         launch_step(c, e, s.nb_edge, s.s_edge);
         HIP_TRY(hipGetLastError());
-        if (s.rows > 4) {
+        if (s.rows > 2 * s.edge_rows) {
           StepArgs m = base_args(c, s, src, !last);
-          m.y_begin = s.row0 + 2; m.y_count = s.rows - 4; m.y_split = m.y_count; m.y_begin2 = 0;
+          m.y_begin = s.row0 + s.edge_rows; m.y_count = s.rows - 2 * s.edge_rows; m.y_split = m.y_count; m.y_begin2 = 0;
           m.partials = slot1;
           launch_step(c, m, s.nb_main, s.s_main);
           HIP_TRY(hipGetLastError());
@@ -732,7 +760,7 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   HIP_TRY(hipEventCreate(&s.ev_t0));
   HIP_TRY(hipEventCreate(&s.ev_t1));
   HIP_TRY(hipEventCreateWithFlags(&s.ev_aux, hipEventDisableTiming));
-  s.row0 = multi ? 2 : 0;
+  s.row0 = multi ? c->halo_depth : 0;
   s.ext_rows = s.rows + 2 * s.row0;
   // row-interleaved SoA (see d2q9_kernels.h): plane-rows padded to whole 256-B lines
   s.plane_stride = ((size_t)(nx + 63) / 64) * 64;
@@ -756,13 +784,12 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   }
   // the accelerated row ny-2 (kernels.cl:18) in stored-row coordinates
   s.accel_own = s.accel_ext = -1;
-  for (int e = std::max(0, s.row0 - 1); e <= std::min(s.ext_rows - 1, s.row0 + s.rows); e++) {
+  for (int e = 0; e < s.ext_rows; e++) {
     const int gy = ((s.y0 - s.row0 + e) % ny + ny) % ny;
     if (gy != ny - 2) continue;
     if (e >= s.row0 && e < s.row0 + s.rows) s.accel_own = e;
-    if (multi || s.accel_own == e) s.accel_ext = e;
+    if (s.accel_ext < 0 || s.accel_own == e) s.accel_ext = e;  // (stored rows repeat only if ext_rows > ny: excluded at creation)
   }
-  if (!multi) s.accel_ext = s.accel_own;
   if (dev_alloc(&s.av_sum, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
   s.fin_blocks = std::max(1, std::min(div_up((long)nx * s.rows, kBlock), 2048));
   if (dev_alloc(&s.fin_partials, (size_t)s.fin_blocks)) return LBM_ERR_HIP;
@@ -836,6 +863,14 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
   // is its own north and south neighbour) — lets a 1-GPU box exercise the RCCL transport end to end
   const char *force = getenv("LBM_FORCE_HALO");
   c->halo_mode = nslabs_global > 1 || (force && atoi(force) != 0);
+  {
+    // halo depth: small slabs are launch-bound and use the LDS multi-step kernel with 8 steps per exchange
+    const int rows_min = params->ny / nslabs_global;
+    const bool small = (long)params->nx * rows_min <= 540L * 1024;
+    c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : 2;
+    if (const char *hd = getenv("LBM_HALO_DEPTH")) c->halo_depth = std::max(2, std::min(kMultiMaxT, atoi(hd)));
+    if (rows_min < 2 * c->halo_depth) c->halo_depth = 2;
+  }
   c->rank_mode = rank_mode;
   c->rank = rank;
   c->vec4 = (params->nx % 4 == 0);

@@ -20,6 +20,7 @@ p = lbm_amd.make_params(nx, ny, nsteps, obstacles=ob)
 
 with lbm_amd.LBM(p, ob) as sim:
     sim.set_option("fuse", 0)
+    sim.set_option("multistep", 0)
     sim.upload(cells0)
     sim.run(nsteps)
     ref, av_ref = sim.download()
@@ -27,16 +28,17 @@ with lbm_amd.LBM(p, ob) as sim:
 
 os.environ["LBM_FORCE_HALO"] = "1"
 os.environ["LBM_TRANSPORT"] = transport
-for fuse in (0, 1):
+for (fuse, ms) in ((0, 0), (1, 0), (0, 8), (0, 5)):  # one / two / eight / five timesteps per launch set (halo depth 8)
     kw = dict(rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) if transport == "rccl" else dict(devices=[0])
     with lbm_amd.LBM(p, ob, **kw) as sim:
         assert sim.get_option("transport") == (1 if transport == "rccl" else 2)
         sim.set_option("fuse", fuse)
+        sim.set_option("multistep", ms)
         sim.upload(cells0)
         sim.run(nsteps)
         got, av = sim.download()   # rank mode: av_vels go through ncclAllReduce
         re = sim.reynolds()
-    assert np.array_equal(got, ref), "state differs (transport %s, fuse %d)" % (transport, fuse)
+    assert np.array_equal(got, ref), "state differs (transport %s, fuse %d, multistep %d)" % (transport, fuse, ms)
     assert np.max(np.abs(av - av_ref) / av_ref) < 2e-6
     assert abs(re / re_ref - 1) < 1e-5
 print("self-ring ok:", transport)

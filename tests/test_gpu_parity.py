@@ -270,11 +270,12 @@ def test_final_state_and_reynolds(lbm, oracle_f32):
 
 # ---- row partition on one GPU (several slabs on device 0, halos by device-to-device copies) ----------
 
-@pytest.mark.parametrize("nslabs,ny", [(2, 50), (3, 50), (8, 50), (2, 16), (4, 67), (5, 128)])
-@pytest.mark.parametrize("fuse", [0, 1])
-def test_row_slabs_equal_single_slab(lbm, nslabs, ny, fuse):
-    """several slabs on one GPU (halo rows exchanged by device-to-device copies) against one slab, with one
-    and with two timesteps per launch; 37 steps = 18 two-step launch sets + one single step"""
+@pytest.mark.parametrize("nslabs,ny", [(2, 50), (3, 50), (8, 50), (2, 16), (4, 67), (5, 128), (2, 260)])
+@pytest.mark.parametrize("mode", ["single", "fused2", "multi8", "multi3", "auto"])
+def test_row_slabs_equal_single_slab(lbm, nslabs, ny, mode):
+    """several slabs on one GPU (halo rows exchanged by device-to-device copies) against one slab, with one,
+    two and up to eight timesteps per launch set (halo depth 2 or 8); 37 steps = full launch sets + a remainder"""
+    opts = {"single": SINGLE, "fused2": FUSED2, "multi8": {"multistep": 8}, "multi3": {"multistep": 3}, "auto": {}}[mode]
     rng = np.random.default_rng(5)
     nx, nsteps = 256, 37
     ob, cells0 = random_case(rng, nx, ny)
@@ -282,7 +283,7 @@ def test_row_slabs_equal_single_slab(lbm, nslabs, ny, fuse):
     ob[-1, :] = 0  # open top/bottom: the y wrap-around between the last and the first slab carries flow
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
-    many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": fuse}, devices=[0] * nslabs)
+    many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, opts, devices=[0] * nslabs)
     assert np.array_equal(one, many)                 # per-cell arithmetic is identical
     assert max_rel(av_many, av_one) < 2e-6           # only the summation order of av_vels differs
 
@@ -306,7 +307,7 @@ def test_row_slabs_large_fused(lbm):
     ob, cells0 = random_case(rng, nx, ny, blocked=0.02)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
-    many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, {"fuse": 1}, devices=[0, 0, 0, 0])
+    many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, FUSED2, devices=[0, 0, 0, 0])
     assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
 
 
