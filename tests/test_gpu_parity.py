@@ -429,3 +429,28 @@ def test_8192x8192_vs_oracle_and_mass(lbm, oracle_f32_omp):
         got, av = sim.download()
     assert abs(got.astype(np.float64).sum() / m0 - 1.0) < 58 * 6e-8
     assert np.all(np.diff(av[:40]) > 0)  # the lid keeps accelerating the cavity from rest
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` (small grid here)"""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "8", "--nx", "1024",
+                        "--ny", "1024", "--no-extra"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 40 and j["warmup"] == 8 and j["higher_is_better"] is True
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and j["vs_baseline"] is None and "workload" in j["config"]
+    assert abs(j["value"] - 1024 * 1024 / (j["ms_per_step"] * 1e-3) / 1e6) / j["value"] < 0.01
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["launch_us"] * 1e-6) / 1e9) / rf["achieved"] < 0.01
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1 and cb["unit"] == "MLUPS" and cb["sample"]
+    assert j["result_ok"] is True
