@@ -556,14 +556,15 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------
 // Grids of a few hundred cells a side are bound by launch latency, not bandwidth (one step of 128x128 is
 // ~2 us of work behind ~3.4 us of launch cost).  This kernel advances T <= kMultiMaxT steps per launch: a
-// workgroup loads a (kMultiTX + 2T) x (kMultiTY + 2T) region around its output tile into LDS, performs T
+// workgroup loads a (TX + 2T) x (TY + 2T) region around its TX x TY output tile into LDS, performs T
 // stream+collide steps LDS -> LDS on a region that shrinks by one cell per step (halo cells are computed
 // redundantly by the neighbouring tiles), and stores the central tile.  Same per-cell arithmetic
 // (collide_cell / accelerate_cell) as the other kernels, so the results are bit-identical.
 constexpr int kMultiMaxT = 8;
-constexpr int kMultiTX = 32, kMultiTY = 16;
-constexpr int kMultiRX = kMultiTX + 2 * kMultiMaxT, kMultiRY = kMultiTY + 2 * kMultiMaxT;  // 48 x 32
 constexpr int kMultiThreads = 1024;
+// Output tile TX x TY (template): 32x16 when the grid has enough tiles to fill the CUs, 16x16 or 16x8 for the
+// smallest grids — a sub-step is VALU-bound on the tile's one CU (~110 instructions per cell on 4 SIMDs), so a
+// grid that cannot fill 256 CUs anyway runs faster on more, smaller tiles despite their larger share of halo cells.
 
 struct MultiArgs {
   const float *src;
@@ -583,7 +584,9 @@ struct MultiArgs {
   float omega, aw1, aw2;
 };
 
+template <int kMultiTX, int kMultiTY>
 __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
+  constexpr int kMultiRX = kMultiTX + 2 * kMultiMaxT, kMultiRY = kMultiTY + 2 * kMultiMaxT;
   __shared__ float lds[2][9][kMultiRY * kMultiRX];
   __shared__ uint8_t lmask[kMultiRY * kMultiRX];
   __shared__ float wsum[kMultiMaxT][kMultiThreads / 64];

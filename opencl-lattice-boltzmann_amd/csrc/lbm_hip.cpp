@@ -127,6 +127,7 @@ struct Slab {
   FuseGeom f_main, f_edge;        // whole slab (one slab) or interior chunks; the two edge chunks
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
+  int m_tx = 32, m_ty = 16;          // its tile size (chosen by how many tiles the slab gives)
   double *av_sum = nullptr;   // [capacity] per-step sum of |j|/rho over this slab's fluid cells
   hipStream_t s_main = nullptr, s_edge = nullptr;
   hipEvent_t ev_main[2] = {nullptr, nullptr};   // interior launch of a launch set done
@@ -162,6 +163,7 @@ struct lbm_ctx {
   int nt_stores = -1;
   int nt_loads = -1;        // non-temporal source loads in d2q9_step2: -1 auto (with nt stores), 0 off, 1 on
   int fuse = -1;            // two timesteps per launch (d2q9_step2): -1 auto, 0 off, 1 on
+  int tile_shape = -1;      // d2q9_multi tile: -1 auto, 0 = 32x16, 1 = 16x16, 2 = 16x8
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
   int chunk_min = 0;        // shortest chunk at the tapered end of a band (0 = auto)
@@ -296,8 +298,21 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     s.nb_edge = 0;
   }
   s.nb_total = s.nb_main + s.nb_edge;
-  s.m_tiles_x = div_up(c->p.nx, kMultiTX);
-  s.m_tiles_y = div_up(s.rows, kMultiTY);
+  // tile size of d2q9_multi: the largest of 32x16, 16x16, 16x8 that still gives ~one tile per two CUs
+  {
+    static const int shapes[3][2] = {{32, 16}, {16, 16}, {16, 8}};
+    // measured (tools/ab_tiles.py, us/step at T = 8 for 32x16 / 16x16 / 16x8): 128x128 1.85 / 1.55 / 1.38,
+    // 128x256 1.94 / 1.63 / 1.49, 256x256 1.97 / 1.85 / 2.07, 384x384 3.86 / 3.46 / 4.25, 512x512 3.89 / 4.12 / 6.18
+    const long t32 = (long)div_up(c->p.nx, 32) * div_up(s.rows, 16);
+    int pick = t32 <= 64 ? 2 : (t32 <= 384 ? 1 : 0);
+    if (c->tile_shape >= 0) pick = std::min(2, c->tile_shape);
+    // slab mode: the edge tile rows must cover the halo depth
+    if (multi && shapes[pick][1] < c->halo_depth) pick = 1;
+    s.m_tx = shapes[pick][0];
+    s.m_ty = shapes[pick][1];
+  }
+  s.m_tiles_x = div_up(c->p.nx, s.m_tx);
+  s.m_tiles_y = div_up(s.rows, s.m_ty);
   if ((long)s.m_tiles_x * s.m_tiles_y <= 65536) s.nb_total = std::max(s.nb_total, s.m_tiles_x * s.m_tiles_y);
   if (fuse_possible(c)) {
     const int q4 = c->p.nx / 4;
@@ -456,6 +471,13 @@ MultiArgs base_args_multi(const lbm_ctx *c, const Slab &s, int src, int T, bool 
   return a;
 }
 
+void launch_multi(const Slab &s, const MultiArgs &a, int tile_rows, hipStream_t st) {
+  const dim3 grid(s.m_tiles_x * tile_rows), block(kMultiThreads);
+  if (s.m_tx == 32) hipLaunchKernelGGL((d2q9_multi<32, 16>), grid, block, 0, st, a);
+  else if (s.m_ty == 16) hipLaunchKernelGGL((d2q9_multi<16, 16>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((d2q9_multi<16, 8>), grid, block, 0, st, a);
+}
+
 void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t st) {
   // Non-temporal loads AND stores by default at every size this kernel is used for: each source value is
   // read once (boundary rows twice, by the neighbouring chunk at the same time) and each result is not read
@@ -601,7 +623,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           MultiArgs a = base_args_multi(c, s, src, adv, !last);
           a.partials = slot1;
           a.ty_begin = 0; a.ty_split = s.m_tiles_y; a.ty_begin2 = 0;
-          hipLaunchKernelGGL(d2q9_multi, dim3(s.m_tiles_x * s.m_tiles_y), dim3(kMultiThreads), 0, s.s_main, a);
+          launch_multi(s, a, s.m_tiles_y, s.s_main);
         } else if (kind == KIND_FUSED2) {
           Step2Args a = base_args2(c, s, src, !last, s.f_main);
           a.partials1 = slot1;
@@ -625,18 +647,18 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
         // edge = the tile rows that hold the halo_depth bottom and top rows (what the neighbours receive):
         // tile row 0 and the tile rows from t_top up; interior = tile rows 1 .. t_top-1
         const int m = s.m_tiles_y;
-        const int t_top = std::max(1, std::min(m, (s.rows - s.edge_rows) / kMultiTY));
+        const int t_top = std::max(1, std::min(m, (s.rows - s.edge_rows) / s.m_ty));
         const int edge_trows = 1 + (m - t_top), int_trows = t_top - 1;
         MultiArgs e = base_args_multi(c, s, src, adv, !last);
         e.partials = slot1 + (size_t)int_trows * s.m_tiles_x;
         e.ty_begin = 0; e.ty_split = 1; e.ty_begin2 = t_top;
-        hipLaunchKernelGGL(d2q9_multi, dim3(s.m_tiles_x * edge_trows), dim3(kMultiThreads), 0, s.s_edge, e);
+        launch_multi(s, e, edge_trows, s.s_edge);
         HIP_TRY(hipGetLastError());
         if (int_trows > 0) {
           MultiArgs mm = base_args_multi(c, s, src, adv, !last);
           mm.partials = slot1;
           mm.ty_begin = 1; mm.ty_split = int_trows; mm.ty_begin2 = 0;
-          hipLaunchKernelGGL(d2q9_multi, dim3(s.m_tiles_x * int_trows), dim3(kMultiThreads), 0, s.s_main, mm);
+          launch_multi(s, mm, int_trows, s.s_main);
           HIP_TRY(hipGetLastError());
         }
       } else if (kind == KIND_FUSED2) {
@@ -1149,6 +1171,12 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   if (!strcmp(key, "nt_stores")) { c->nt_stores = (int)value; return LBM_OK; }
   if (!strcmp(key, "nt_loads")) { c->nt_loads = (int)value; return LBM_OK; }
   if (!strcmp(key, "fuse")) { c->fuse = (int)value; return LBM_OK; }
+  if (!strcmp(key, "tile_shape")) {
+    if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "tile_shape must be -1..2");
+    if (int rc = sync_all(c)) return rc;
+    c->tile_shape = (int)value;
+    return rebuild_geometry(c);
+  }
   if (!strcmp(key, "multistep")) {
     if (value < -1 || value > kMultiMaxT) return fail(LBM_ERR_ARG, "multistep must be -1..%d", kMultiMaxT);
     c->multistep = (int)value;
