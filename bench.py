@@ -134,6 +134,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # one GPU per rank; if the launcher narrowed the visible devices per rank, index within what is visible
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = init_dist("nccl", rank, world, torch.device("cuda", local_rank)) if world > 1 else None
 
