@@ -436,7 +436,9 @@ __device__ __forceinline__ float first_step_row(const Step2Args &a, const RowLoa
   return collide4(g, in.m, a.omega, r == a.accel_row, a.aw1, a.aw2, I);
 }
 
-template <bool NT, bool NTL = false>
+// NTL: 0 = plain source loads, 1 = all non-temporal, 2 = non-temporal except for the two intermediate rows at
+// either end of a chunk, whose source rows the neighbouring chunk reads as well (they should stay in L2)
+template <bool NT, int NTL = 0>
 __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   const int lane = threadIdx.x;
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one, MI355X_MICROARCH.md), so
@@ -481,8 +483,8 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   // two row-sets of source loads are kept in flight (ping-pong) so that HBM latency is covered by
   // both collision passes of an iteration
   RowLoads inA, inB;
-  issue_row_loads<NTL>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, inA);
-  issue_row_loads<NTL>(a, wrap(r0 + d), xcol, xhalo_w, xhalo_e, lane, inB);
+  issue_row_loads<NTL == 1>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, inA);
+  issue_row_loads<NTL == 1>(a, wrap(r0 + d), xcol, xhalo_w, xhalo_e, lane, inB);
 #pragma unroll
   for (int v = 0; v < 4; v++) {
     trail[0][v] = trail[1][v] = trail[2][v] = 0.f;
@@ -495,7 +497,10 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
     const float t1 = first_step_row(a, in, wrap(r0 + k * d), top);
     m_top = in.m;
     if (owner && k >= 1 && k <= n) sum1 += t1;  // rows k = 0 and n+1 belong to the neighbouring chunks
-    if (k + 2 <= n + 1) issue_row_loads<NTL>(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    if (k + 2 <= n + 1) {
+      if (NTL == 2 && k + 2 < n) issue_row_loads<true>(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      else issue_row_loads<NTL == 1>(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    }
     // step t+2 of the middle row of the window (complete from the third iteration on); y-shifted values come
     // from this lane's own registers, x-shifted ones by DPP
     if (k >= 2) {

@@ -479,17 +479,16 @@ void launch_multi(const Slab &s, const MultiArgs &a, int tile_rows, hipStream_t 
 }
 
 void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t st) {
-  // Non-temporal stores always (a result is not read again before the next launch).  Non-temporal LOADS only
-  // while both grids fit the Infinity Cache: beyond it they cost HBM traffic — the boundary rows that
-  // neighbouring chunks share are no longer kept in L2 (PMC on 8192x8192: 5.13 GB per launch with plain loads,
-  // 5.90 GB with nt loads), which caps the kernel at ~144 GLUPS (5.9 GB at the 6.3 TB/s the memory system
-  // delivers) where plain loads reach 139-162 GLUPS depending on the device's clock (profiles/r01g vs r01h/r01i).
-  // In-cache grids gain from nt loads (1024x1024 +12.7 %, tools/ab_head.py).
+  // Non-temporal stores always (a result is not read again before the next launch).  Source loads: HYBRID —
+  // non-temporal (lower latency, no cache pollution) for the rows only this chunk reads, plain for the two
+  // intermediate rows at either end of the chunk, whose source rows the neighbouring chunk reads at the same
+  // time and should find in L2.  All-nt loads lose that reuse (PMC on 8192x8192: 5.90 GB per launch instead
+  // of 5.13 GB).  Same-box A/B (tools/ab_head.py), plain / all-nt / hybrid in GLUPS: 8192x8192 136 / 140 / 153,
+  // 4096x4096 126 / 133 / 147, 2048x2048 110 / 117 / 128, 1024x1024 82 / 102 / 113.
   const bool nts = c->nt_stores >= 0 ? c->nt_stores != 0 : true;
-  const size_t grid_bytes = c->slabs[0].row_stride * c->slabs[0].ext_rows * sizeof(float);
-  const bool in_cache = 2 * grid_bytes <= ((size_t)192 << 20);
-  const bool ntl = c->nt_loads >= 0 ? c->nt_loads != 0 : (nts && in_cache);
-  if (ntl) hipLaunchKernelGGL((d2q9_step2<true, true>), dim3(units), dim3(64), 0, st, a);
+  const int ntl = c->nt_loads >= 0 ? c->nt_loads : (nts ? 2 : 0);
+  if (ntl == 2) hipLaunchKernelGGL((d2q9_step2<true, 2>), dim3(units), dim3(64), 0, st, a);
+  else if (ntl == 1) hipLaunchKernelGGL((d2q9_step2<true, 1>), dim3(units), dim3(64), 0, st, a);
   else if (nts) hipLaunchKernelGGL((d2q9_step2<true>), dim3(units), dim3(64), 0, st, a);
   else hipLaunchKernelGGL((d2q9_step2<false>), dim3(units), dim3(64), 0, st, a);
 }
