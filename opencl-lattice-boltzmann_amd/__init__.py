@@ -17,7 +17,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "liblbm_hip.so")
+LIB_PATH = os.path.join(PKG_DIR, os.environ.get("LBM_LIB", "liblbm_hip.so"))  # LBM_LIB: A/B of two builds (tools/ab_two_libs.py)
 
 # every symbol include/lbm.h declares
 ABI_SYMBOLS = [
