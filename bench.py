@@ -72,9 +72,18 @@ def cpu_baseline(nx, ny, obstacles, accel, budget_s=15.0):
         el = time.perf_counter() - t0
         if n >= 2 and (el > budget_s or n >= 64):
             break
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": round(nx * ny * n / el / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "port",
             "sample": "%d timesteps of the same %dx%d grid with the serial fp32 oracle "
-                      "(oracle/d2q9_oracle.c, gcc -O3 -march=native, 1 of %d host cores)" % (n, nx, ny, os.cpu_count())}
+                      "(oracle/d2q9_oracle.c, gcc -O3 -march=native, 1 of %d host cores, %s)" % (n, nx, ny, os.cpu_count(), model)}
 
 
 # ---- torch.distributed plumbing (also exercised with the gloo backend on CPU: tests/test_multirank_gloo.py) ----
