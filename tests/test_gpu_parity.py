@@ -454,3 +454,39 @@ def test_bench_json_contract():
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1 and cb["unit"] == "MLUPS" and cb["sample"]
     assert j["result_ok"] is True
+
+
+def test_abi_error_behaviour(lbm):
+    """non-zero return codes + lbm_last_error() messages instead of the reference's print-and-exit (d2q9-bgk.c:858-866)"""
+    import ctypes
+    lib = lbm.load_library()
+    ob = np.zeros((8, 8), np.int32)
+    ctx = ctypes.c_void_p()
+    bad = lbm.make_params(2, 8, 4)
+    assert lib.lbm_create(ctypes.byref(ctx), ctypes.byref(bad), ob.ctypes.data, 1, None) == 1  # LBM_ERR_ARG
+    assert b"at least 3x3" in lib.lbm_last_error() and not ctx.value
+    p = lbm.make_params(8, 8, 4, obstacles=ob)
+    assert lib.lbm_create(ctypes.byref(ctx), ctypes.byref(p), None, 1, None) == 1
+    devs = (ctypes.c_int * 1)(99)
+    assert lib.lbm_create(ctypes.byref(ctx), ctypes.byref(p), ob.ctypes.data, 1, devs) == 1
+    assert b"out of range" in lib.lbm_last_error()
+    two = (ctypes.c_int * 2)(0, 0)
+    assert lib.lbm_create(ctypes.byref(ctx), ctypes.byref(p), ob.ctypes.data, 2, two) == 0  # 4 rows per slab: allowed
+    lib.lbm_destroy(ctx)
+    three = (ctypes.c_int * 3)(0, 0, 0)
+    assert lib.lbm_create(ctypes.byref(ctx), ctypes.byref(p), ob.ctypes.data, 3, three) == 1  # 2 rows per slab: refused
+    assert b"rows per slab" in lib.lbm_last_error()
+    with lbm.LBM(p, ob) as sim:
+        with pytest.raises(lbm.LBMError, match="unknown option"):
+            sim.set_option("no_such_knob", 1)
+        with pytest.raises(lbm.LBMError):
+            sim.set_option("variant", 9)
+        with pytest.raises(lbm.LBMError, match="max_iters"):
+            sim.run(5)
+        sim.run(4)
+        assert sim.steps_done == 4 and sim.row_range() == (0, 8)
+        sim.upload(None)
+        assert sim.steps_done == 0  # upload resets the step counter
+        sim.run(0)
+        _, av = sim.download(cells=False)
+        assert av.size == 0
