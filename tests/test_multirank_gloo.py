@@ -1,7 +1,8 @@
-"""World-size-2 (and 3) `gloo` rehearsal of the row partition on CPU: every rank steps its slab with the
-oracle's row kernels, exchanges the three distributions that cross each slab edge with its ring
-neighbours and all-reduces the velocity sums — exactly the protocol liblbm_hip.so runs per GPU with
-RCCL (csrc/lbm_hip.cpp: run_steps / exchange_halos).  The result must equal the undivided oracle run."""
+"""World-size 2-4 `gloo` rehearsal of the row partition on CPU: every rank steps its slab with the oracle's
+row kernels, exchanges halo rows with its ring neighbours every `depth` steps (recomputing a shrinking
+halo region in between) and all-reduces the velocity sums — the protocol liblbm_hip.so runs per GPU with
+RCCL (csrc/lbm_hip.cpp: run_steps / exchange_halos) for halo depths 1, 2 (two-step kernel) and 8
+(d2q9_multi).  The result must equal the undivided oracle run bit for bit."""
 import os
 import socket
 import sys
@@ -18,7 +19,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, size, nsteps, out_dir):
+def _rank_main(rank, world, port, size, nsteps, depth, out_dir):
+    """One rank of the row partition with halo depth `depth`: the slab stores `depth` halo rows below and above its
+    own rows, exchanges them every `depth` steps and in between recomputes a halo region that shrinks by one row per
+    step — depth 1 is the classic per-step exchange, 2 what the two-step kernel needs, 8 what d2q9_multi uses."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,53 +37,62 @@ def _rank_main(rank, world, port, size, nsteps, out_dir):
     nx, ny = pg.nx, pg.ny
     y0, rows = lbm_amd.slab_rows(ny, world, rank)
     south, north = lbm_amd.ring_neighbours(world, rank)
-    accel_row = lbm_amd.accel_row_local(ny, y0, rows)
-    # local grid with one halo row below and above: local row i <-> global row y0 + i - 1
-    L = rows + 2
+    H = depth
+    L = rows + 2 * H                      # stored rows: stored row e <-> global row (y0 - H + e) mod ny
+    gy = [(y0 - H + e) % ny for e in range(L)]
     p = orc.make_params(nx, L, nsteps, pg.reynolds_dim, pg.density, pg.accel, pg.omega)
-    ob = np.zeros((L, nx), dtype=np.int32)
-    ob[1:-1] = obst[y0:y0 + rows]
+    ob = np.ascontiguousarray(obst[gy])   # halo rows carry the neighbours' obstacle flags
     cur = np.zeros((9, L, nx), dtype=np.float32)
-    cur[:, 1:-1] = orc.init_cells(pg)[:, y0:y0 + rows]
+    cur[:, H:H + rows] = orc.init_cells(pg)[:, y0:y0 + rows]
     nxt = np.zeros_like(cur)
     sums = np.zeros(nsteps, dtype=np.float64)
 
     def exchange(grid):
-        # planes 2,5,6 of my top row feed the north neighbour's south halo; 4,7,8 of my bottom row feed the
-        # south neighbour's north halo (lbm_amd.HALO_PLANES mirrors exchange_halos in csrc/lbm_hip.cpp)
-        up = torch.from_numpy(np.ascontiguousarray(grid[lbm_amd.HALO_PLANES["to_north"], rows]))
-        down = torch.from_numpy(np.ascontiguousarray(grid[lbm_amd.HALO_PLANES["to_south"], 1]))
+        # my top `depth` rows feed the north neighbour's south halo, my bottom rows the south neighbour's north halo
+        # (whole rows, as exchange_halos in csrc/lbm_hip.cpp sends them; lbm_amd.HALO_PLANES names the planes that
+        # actually cross the edge in a single step)
+        up = torch.from_numpy(np.ascontiguousarray(grid[:, rows:rows + H]))
+        down = torch.from_numpy(np.ascontiguousarray(grid[:, H:2 * H]))
         from_s, from_n = torch.empty_like(up), torch.empty_like(down)
         reqs = [dist.isend(up, north, tag=1), dist.isend(down, south, tag=2),
                 dist.irecv(from_s, south, tag=1), dist.irecv(from_n, north, tag=2)]
         for r in reqs:
             r.wait()
-        grid[lbm_amd.HALO_PLANES["to_north"], 0] = from_s.numpy()
-        grid[lbm_amd.HALO_PLANES["to_south"], rows + 1] = from_n.numpy()
+        grid[:, 0:H] = from_s.numpy()
+        grid[:, H + rows:] = from_n.numpy()
 
-    for t in range(nsteps):
-        if accel_row >= 0:
-            orc.accelerate_row(p, cur, ob, accel_row + 1)
+    t = 0
+    while t < nsteps:
         exchange(cur)
-        sums[t] = orc.timestep_rows(p, cur, nxt, ob, 1, rows + 1)
-        cur, nxt = nxt, cur
+        for s in range(1, min(H, nsteps - t) + 1):
+            # accelerate_flow acts on EVERY stored copy of global row ny-2 that is still inside the valid region
+            for e in range(s - 1, L - s + 1):
+                if gy[e] == ny - 2:
+                    orc.accelerate_row(p, cur, ob, e)
+            # the valid region shrinks by one row per step; only the slab's own rows count for av_vels
+            orc.timestep_rows(p, cur, nxt, ob, s, H)
+            sums[t] = orc.timestep_rows(p, cur, nxt, ob, H, H + rows)
+            orc.timestep_rows(p, cur, nxt, ob, H + rows, L - s)
+            cur, nxt = nxt, cur
+            t += 1
     tot = torch.from_numpy(sums.copy())
     dist.all_reduce(tot)  # the per-rank partial velocity sums (ncclAllReduce in the library)
     av = (tot.numpy() * float(pg.free_cells_inv)).astype(np.float32)
-    np.save(os.path.join(out_dir, "cells_%d.npy" % rank), cur[:, 1:-1])
+    np.save(os.path.join(out_dir, "cells_%d.npy" % rank), cur[:, H:H + rows])
     if rank == 0:
         np.save(os.path.join(out_dir, "av.npy"), av)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,nsteps", [(2, "128x128", 40), (3, "128x256", 25)])
-def test_row_partition_protocol_matches_undivided_run(tmp_path, world, size, nsteps):
+@pytest.mark.parametrize("world,size,nsteps,depth", [(2, "128x128", 40, 1), (3, "128x256", 25, 1), (2, "128x128", 21, 2),
+                                                     (2, "128x256", 27, 8), (4, "128x256", 16, 8)])
+def test_row_partition_protocol_matches_undivided_run(tmp_path, world, size, nsteps, depth):
     import torch.multiprocessing as mp
     import lbm_amd
     from oracle.oracle import Oracle
 
-    mp.spawn(_rank_main, args=(world, _free_port(), size, nsteps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), size, nsteps, depth, str(tmp_path)), nprocs=world, join=True)
     orc = Oracle("f32")
     p, obst = orc.load(*input_files(size))
     ref = orc.init_cells(p)
