@@ -490,3 +490,18 @@ def test_abi_error_behaviour(lbm):
         sim.run(0)
         _, av = sim.download(cells=False)
         assert av.size == 0
+
+
+@pytest.mark.parametrize("nx,ny", [(8200, 300), (4100, 517), (5000, 333), (16384, 130), (260, 4099)])
+def test_odd_large_shapes_all_kernels_agree(lbm, nx, ny):
+    """row lengths that are no multiple of a wave's 256 cells, row counts that no chunk size divides, very wide and
+    very tall grids: the two-step kernel, the LDS multi-step kernel and four slabs agree with single steps bit for bit"""
+    rng = np.random.default_rng(nx + ny)
+    ob, cells0 = random_case(rng, nx, ny, blocked=0.03)
+    nsteps = 7
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    base, av_base = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    for opts, kw in ((FUSED2, {}), ({"multistep": 4}, {}), (FUSED2, {"devices": [0, 0, 0, 0]}), ({}, {"devices": [0, 0]})):
+        got, av = run_gpu(lbm, p, ob, cells0, nsteps, opts, **kw)
+        assert np.array_equal(got, base), (opts, kw)
+        assert max_rel(av, av_base) < 2e-6
