@@ -81,7 +81,25 @@ def cpu_baseline(nx, ny, obstacles, accel, budget_s=15.0):
                     break
     except OSError:
         pass
-    return {"value": round(nx * ny * n / el / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "port",
+    # the same oracle with OpenMP over this process's CPU share, as a second reference point (a few steps only)
+    omp = None
+    try:
+        threads = max(1, min(16, len(os.sched_getaffinity(0))))
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        orc_omp = Oracle("f32", omp=True)
+        p_omp = orc_omp.make_params(nx, ny, 1, 10, 0.1, accel, 1.85)
+        orc_omp.set_obstacles(p_omp, obstacles)
+        orc_omp.timestep(p_omp, src, dst, obstacles)
+        m, t1 = 0, time.perf_counter()
+        while m < 2 or (time.perf_counter() - t1 < 4.0 and m < 64):
+            orc_omp.accelerate_flow(p_omp, src, obstacles)
+            orc_omp.timestep(p_omp, src, dst, obstacles)
+            src, dst = dst, src
+            m += 1
+        omp = {"value": round(nx * ny * m / (time.perf_counter() - t1) / 1e6, 1), "cores": threads, "steps": m}
+    except Exception:  # the baseline is informational; never fail the bench over it
+        omp = None
+    return {"value": round(nx * ny * n / el / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "port", "openmp": omp,
             "sample": "%d timesteps of the same %dx%d grid with the serial fp32 oracle "
                       "(oracle/d2q9_oracle.c, gcc -O3 -march=native, 1 of %d host cores, %s)" % (n, nx, ny, os.cpu_count(), model)}
 
