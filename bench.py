@@ -241,6 +241,11 @@ def main():
                 out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_frac"] = round(tj[key]["hbm_bytes_per_launch"] / launch_s / 1e9 / HBM_PEAK_GBPS, 4)
                 out["roofline"]["traffic_source"] = tj[key].get("source")
+        # what a plain float4 copy achieves on this box right now (context for `frac`; the spec peak stays `peak`)
+        try:
+            out["roofline"]["copy_kernel_gbps"] = round(lbm_amd.copy_bandwidth_gbps(1 << 30, 10), 1)
+        except lbm_amd.LBMError:
+            pass
         if fused:
             out["roofline"]["note"] = ("frac uses the ALGORITHMIC 72 B per lattice update; the two-step kernel keeps the "
                                        "intermediate state in registers and really moves ~43 B per update (traffic), so frac "

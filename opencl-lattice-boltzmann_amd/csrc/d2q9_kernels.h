@@ -70,6 +70,16 @@ __device__ __forceinline__ void store4(float *p, float a, float b, float c, floa
   else *reinterpret_cast<v4f *>(p) = v;
 }
 
+// 16-byte load, non-temporal when the data is read exactly once (grids beyond the Infinity Cache)
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float *p) {
+  if (NT) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const float4 *>(p);
+}
+
 // BGK collision of one cell on the gathered distributions g[0..8]; writes the new cell to out[].
 // Returns |j|/rho for a fluid cell, 0 for an obstacle.  Arithmetic of kernels.cl:119-198 with
 //  - momenta from pairwise differences (a cell at rest has exactly zero momentum in fp32),
@@ -231,9 +241,9 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
     uint32_t mask_word = 0;
     if constexpr (VEC == 4) {
       // all loads are issued before any use
-      const float4 c0 = *reinterpret_cast<const float4 *>(rc + x0);
-      const float4 c2 = *reinterpret_cast<const float4 *>(r2 + x0);
-      const float4 c4 = *reinterpret_cast<const float4 *>(r4 + x0);
+      const float4 c0 = ld4<NT && LM != LM_SCALAR>(rc + x0);
+      const float4 c2 = ld4<NT && LM != LM_SCALAR>(r2 + x0);
+      const float4 c4 = ld4<NT && LM != LM_SCALAR>(r4 + x0);
       const uint32_t m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)y * a.nx + x0);
       g[0][0] = c0.x; g[0][1] = c0.y; g[0][2] = c0.z; g[0][3] = c0.w;
       g[2][0] = c2.x; g[2][1] = c2.y; g[2][2] = c2.z; g[2][3] = c2.w;
@@ -262,12 +272,12 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
         g[6][0] = e6.x; g[6][1] = e6.y; g[6][2] = e6.z; g[6][3] = e6.w;
         g[7][0] = e7.x; g[7][1] = e7.y; g[7][2] = e7.z; g[7][3] = e7.w;
       } else {
-        const float4 c1 = *reinterpret_cast<const float4 *>(r1 + x0);
-        const float4 c3 = *reinterpret_cast<const float4 *>(r3 + x0);
-        const float4 c5 = *reinterpret_cast<const float4 *>(r5 + x0);
-        const float4 c6 = *reinterpret_cast<const float4 *>(r6 + x0);
-        const float4 c7 = *reinterpret_cast<const float4 *>(r7 + x0);
-        const float4 c8 = *reinterpret_cast<const float4 *>(r8 + x0);
+        const float4 c1 = ld4<NT && LM != LM_SCALAR>(r1 + x0);
+        const float4 c3 = ld4<NT && LM != LM_SCALAR>(r3 + x0);
+        const float4 c5 = ld4<NT && LM != LM_SCALAR>(r5 + x0);
+        const float4 c6 = ld4<NT && LM != LM_SCALAR>(r6 + x0);
+        const float4 c7 = ld4<NT && LM != LM_SCALAR>(r7 + x0);
+        const float4 c8 = ld4<NT && LM != LM_SCALAR>(r8 + x0);
         float w1, w5, w8, e3, e6, e7;
         if constexpr (LM == LM_SCALAR) {
           w1 = r1[xw]; w5 = r5[xw]; w8 = r8[xw];
@@ -779,6 +789,16 @@ __global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsig
 // ---- roofline denominator: float4 streaming copy ---------------------------------------------
 __global__ __launch_bounds__(kBlock) void copy_f4(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = in[i];
+}
+
+// the same with the access pattern that proved best for the step kernels: one 4-KiB tile per workgroup,
+// non-temporal loads and stores
+__global__ __launch_bounds__(kBlock) void copy_f4_nt(const float *__restrict__ in, float *__restrict__ out, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n4) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(in) + i);
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(out) + i);
+  }
 }
 
 }  // namespace lbm

@@ -1231,23 +1231,33 @@ int lbm_copy_bandwidth(size_t bytes, int iters, double *gbps) {
   hipEventCreate(&t0);
   hipEventCreate(&t1);
   hipMemset(a, 1, n * 16);
-  const int nb = (int)std::min<size_t>((n + kBlock - 1) / kBlock, 256 * 16);
-  hipLaunchKernelGGL(lbm::copy_f4, dim3(nb), dim3(kBlock), 0, 0, a, b, n);  // warm-up
-  hipEventRecord(t0, 0);
-  for (int i = 0; i < iters; i++) {
-    if (i & 1) hipLaunchKernelGGL(lbm::copy_f4, dim3(nb), dim3(kBlock), 0, 0, b, a, n);
-    else hipLaunchKernelGGL(lbm::copy_f4, dim3(nb), dim3(kBlock), 0, 0, a, b, n);
+  // best of two launch shapes: 4096 grid-striding workgroups with plain accesses, one tile per workgroup with
+  // non-temporal accesses
+  double best = 0.0;
+  for (int shape = 0; shape < 2 && e == hipSuccess; shape++) {
+    const int nb = shape == 0 ? (int)std::min<size_t>((n + kBlock - 1) / kBlock, 256 * 16) : (int)((n + kBlock - 1) / kBlock);
+    auto launch = [&](float4 *src, float4 *dst) {
+      if (shape == 0) hipLaunchKernelGGL(lbm::copy_f4, dim3(nb), dim3(kBlock), 0, 0, src, dst, n);
+      else hipLaunchKernelGGL(lbm::copy_f4_nt, dim3(nb), dim3(kBlock), 0, 0, (const float *)src, (float *)dst, n);
+    };
+    launch(a, b);  // warm-up
+    hipEventRecord(t0, 0);
+    for (int i = 0; i < iters; i++) {
+      if (i & 1) launch(b, a);
+      else launch(a, b);
+    }
+    hipEventRecord(t1, 0);
+    e = hipEventSynchronize(t1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, t0, t1);
+    if (e == hipSuccess && ms > 0.f) best = std::max(best, 2.0 * (double)(n * 16) * iters / (ms * 1e-3) / 1e9);
   }
-  hipEventRecord(t1, 0);
-  e = hipEventSynchronize(t1);
-  float ms = 0.f;
-  hipEventElapsedTime(&ms, t0, t1);
   hipEventDestroy(t0);
   hipEventDestroy(t1);
   hipFree(a);
   hipFree(b);
   if (e != hipSuccess) return fail(LBM_ERR_HIP, "copy kernel: %s", hipGetErrorString(e));
-  *gbps = 2.0 * (double)(n * 16) * iters / (ms * 1e-3) / 1e9;
+  *gbps = best;
   return LBM_OK;
 }
 
