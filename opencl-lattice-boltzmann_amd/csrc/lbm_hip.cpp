@@ -253,7 +253,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     // that just fill the wave slots: every extra unit costs two redundant rows, and a second, partly filled
     // round costs more than it balances (1024x1024: 3-row chunks = 1720 units: 10.2 us/step; 2-row chunks =
     // 2560 units: 12.1; 4-row chunks = 1280 units: 11.6 — tools/ab_1024.py)
-    const int one_round = (int)std::ceil(n / std::floor(slots));
+    const int one_round = (int)std::ceil(n / std::max(1.0, std::floor(slots)));
     const bool single_round = one_round <= cmax;
     while (rem > 0) {
       int sz = single_round ? std::max(2, one_round) : (int)std::ceil(rem / (2.0 * slots));

@@ -492,7 +492,7 @@ def test_abi_error_behaviour(lbm):
         assert av.size == 0
 
 
-@pytest.mark.parametrize("nx,ny", [(8200, 300), (4100, 517), (5000, 333), (16384, 130), (260, 4099)])
+@pytest.mark.parametrize("nx,ny", [(8200, 300), (4100, 517), (5000, 333), (16384, 130), (260, 4099), (65536, 72)])
 def test_odd_large_shapes_all_kernels_agree(lbm, nx, ny):
     """row lengths that are no multiple of a wave's 256 cells, row counts that no chunk size divides, very wide and
     very tall grids: the two-step kernel, the LDS multi-step kernel and four slabs agree with single steps bit for bit"""
