@@ -150,6 +150,8 @@ struct lbm_ctx {
   int nslabs_global = 1;    // slabs in the ring (== slabs.size() unless rank mode)
   bool rank_mode = false;
   bool halo_mode = false;   // slabs carry halo rows and exchange them (more than one slab, or forced for tests)
+  int rows_min = 0;         // smallest slab of the partition (ny / nslabs): every rank takes the size-dependent
+                            // decisions (kernel, halo depth, schedule) from it, so that all ranks take the same ones
   int halo_depth = 2;       // rows exchanged per side and launch set: 2 (two-step kernel) or 8 (LDS multi-step kernel, small slabs)
   int rank = 0;
   int cur = 0;              // index of the grid holding the current state
@@ -209,27 +211,27 @@ void split_rows(int ny, int P, int idx, int *y0, int *rows) {
 // two-steps-per-launch kernel: float4 rows of at least one wave, a few rows per slab
 bool fuse_possible(const lbm_ctx *c) {
   if (!c->vec4 || c->p.nx < 256) return false;
-  for (const Slab &s : c->slabs)
-    if (s.rows < 8) return false;
-  return true;
+  return c->rows_min >= 8;
 }
 bool fuse_effective(const lbm_ctx *c) {
   if (!fuse_possible(c)) return false;
   if (c->fuse >= 0) return c->fuse != 0;
   // auto: from 768x768 up it beats one launch per step (profiles/r01_kernel_choice.txt); smaller grids have too
   // few strip x chunk units to fill 2048 wave slots
-  return (long)c->p.nx * c->slabs[0].rows > 540L * 1024;
+  return (long)c->p.nx * c->rows_min > 540L * 1024;
 }
 
 // LDS multi-step kernel: one slab holding the whole periodic grid; worth it only while the grid is launch-bound
 int multistep_effective(const lbm_ctx *c) {
+  // launch grids stay small (tile count from the smallest tile and the largest slab: identical on every rank)
+  if ((long)div_up(c->p.nx, 16) * div_up(c->rows_min + 1, 8) > 65536) return 0;
   // with halo rows a launch can advance at most as many steps as the halos are deep
   const int cap = c->halo_mode ? std::min(kMultiMaxT, c->halo_depth) : kMultiMaxT;
   if (c->halo_mode && c->halo_depth < kMultiMaxT && c->multistep < 0) return 0;  // big slabs: two-step kernel
   if (c->multistep >= 0) return std::min(c->multistep, cap);
   // auto: up to 1024x512 cells (profiles/r01_kernel_choice.txt: 128x128 1.7 us/step against 3.8 with one launch
   // per step, 1024x512 6.7 against 7.4 for the two-step kernel; from 768x768 on the two-step kernel wins)
-  return ((long)c->p.nx * c->slabs[0].rows <= 540L * 1024) ? cap : 0;
+  return ((long)c->p.nx * c->rows_min <= 540L * 1024) ? cap : 0;
 }
 
 // Work decomposition of d2q9_step2 over stored rows [r0, r1): strips x chunks.  A unit's cost is
@@ -313,7 +315,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
   }
   s.m_tiles_x = div_up(c->p.nx, s.m_tx);
   s.m_tiles_y = div_up(s.rows, s.m_ty);
-  if ((long)s.m_tiles_x * s.m_tiles_y <= 65536) s.nb_total = std::max(s.nb_total, s.m_tiles_x * s.m_tiles_y);
+  if ((long)s.m_tiles_x * s.m_tiles_y <= 65536 * 4) s.nb_total = std::max(s.nb_total, s.m_tiles_x * s.m_tiles_y);
   if (fuse_possible(c)) {
     const int q4 = c->p.nx / 4;
     // x decomposition: lanes 0 and 63 of a wave are halo lanes, so a strip has at most 62 output lanes — but
@@ -328,7 +330,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     }
     // measured optimum (profiles/r01_fused_sweep.txt): short chunks — the rows concurrently in flight on an
     // XCD then fit the caches, which absorbs the re-read boundary rows; 6/2 from 4096x4096 up, 8/4 below
-    const bool big = (long)c->p.nx * s.rows >= 8L << 20;
+    const bool big = (long)c->p.nx * c->rows_min >= 8L << 20;
     int cmax = c->chunk_rows > 0 ? c->chunk_rows : (big ? 6 : 8);
     cmax = std::max(2, std::min(cmax, s.rows));
     const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), cmax));
@@ -605,7 +607,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     const int src = c->cur;
     // timesteps advanced by this launch set, and with which kernel
     int kind = KIND_SINGLE, adv = 1;
-    if (multi_T > 0 && c->slabs[0].m_tiles_x * (long)c->slabs[0].m_tiles_y <= 65536) {
+    if (multi_T > 0) {
       kind = KIND_MULTI;
       adv = std::min(multi_T, nsteps - i);
     } else if (fuse && nsteps - i >= 2) {
@@ -891,6 +893,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
   {
     // halo depth: small slabs are launch-bound and use the LDS multi-step kernel with 8 steps per exchange
     const int rows_min = params->ny / nslabs_global;
+    c->rows_min = rows_min;
     const bool small = (long)params->nx * rows_min <= 540L * 1024;
     c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : 2;
     if (const char *hd = getenv("LBM_HALO_DEPTH")) c->halo_depth = std::max(2, std::min(kMultiMaxT, atoi(hd)));
