@@ -102,7 +102,8 @@ int lbm_sync(lbm_ctx *ctx);
  * pointer may be NULL.  cells_out receives the CURRENT state whatever the step parity (the
  * reference reads a fixed buffer, correct only for even step counts).  av_vels_out receives
  * lbm_steps_done() floats.  Synchronises.  In rank mode cells_out is the GLOBAL array and only
- * this rank's rows are written; av_vels_out is the all-reduced global record.
+ * this rank's rows are written; av_vels_out is the all-reduced global record — asking for it is a
+ * collective operation: every rank must make the same call.  lbm_reynolds is collective in rank mode too.
  */
 int lbm_download(lbm_ctx *ctx, float *cells_out, float *av_vels_out);
 
