@@ -126,8 +126,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  * Tuning knobs (all optional; defaults are the measured-best on MI355X):
  *   "variant"      how a thread gets its x-1/x+1 neighbours: 0 = auto, 1 = scalar L1 loads,
  *                  2 = unaligned 16-byte loads, 3 = wave64 DPP shifts, 4 = LDS-staged row with halo
- *   "fuse"         1 = advance two timesteps per launch (intermediate state kept in registers, half
- *                  the HBM traffic), 0 = one launch per step, -1 = auto.  Single-slab grids only.
+ *   "fuse"         1 (or 2) = advance two timesteps per launch (intermediate state kept in registers, half
+ *                  the HBM traffic), 3 = three timesteps per launch (two register windows, a third of the
+ *                  traffic), 0 = one launch per step, -1 = auto (by grid size).
  *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
  *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)

@@ -376,7 +376,8 @@ struct Step2Args {
   int nchunks;                 // units = strips * nchunks
   int nbands, units_per_band;  // workgroup b works on unit (b % nbands)*units_per_band + b / nbands
   int skip_chunk;              // chunk index whose units do nothing (-1: none); slab mode's edge launch skips the interior
-  int accel_row;               // row ny-2
+  int accel_row;               // stored row that holds global row ny-2 (-1: none)
+  int accel_row_b;             // a second stored copy of it (a slab that is its own ring neighbour), else -1
   int accel_next;              // apply the following step's accelerate_flow to the output row ny-2
   float omega, aw1, aw2;
 };
@@ -443,7 +444,7 @@ __device__ __forceinline__ float first_step_row(const Step2Args &a, const RowLoa
   unpack4(in.c[6], c); shift_from_east(c, in.h1, g[6]);
   unpack4(in.c[7], c); shift_from_east(c, in.h2, g[7]);
   // the intermediate row ny-2 receives step t+2's accelerate_flow before it is streamed (kernels.cl:9-53)
-  return collide4(g, in.m, a.omega, r == a.accel_row, a.aw1, a.aw2, I);
+  return collide4(g, in.m, a.omega, r == a.accel_row || r == a.accel_row_b, a.aw1, a.aw2, I);
 }
 
 // NTL: 0 = plain source loads, 1 = all non-temporal, 2 = non-temporal except for the two intermediate rows at
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
         g[6][v] = up ? a2[v] : b2[v];
         g[7][v] = up ? b2[v] : a2[v];
       }
-      const float t2 = collide4(g, m_mid, a.omega, (y == a.accel_row) && a.accel_next, a.aw1, a.aw2, o);
+      const float t2 = collide4(g, m_mid, a.omega, (y == a.accel_row || y == a.accel_row_b) && a.accel_next, a.aw1, a.aw2, o);
       if (owner) {
         sum2 += t2;
         float *dp = a.dst + (size_t)y * a.row_stride + xcol;
@@ -565,6 +566,151 @@ __global__ __launch_bounds__(64) void d2q9_step2(const Step2Args a) {
   if (lane == 0) {
     a.partials1[unit] = sum1;
     a.partials2[unit] = sum2;
+  }
+}
+
+// ---- three timesteps per launch --------------------------------------------------------------------
+// The same idea one level deeper: TWO register windows (the state after step t+1 and after step t+2), three
+// collision passes per iteration; the grid is read once and written once per THREE steps.  Two halo lanes at
+// either end of a wave (the second window is valid on lanes 1..62, the output on lanes 2..61) and two redundant
+// intermediate rows at either end of a chunk for the first window, one for the second.  Same helpers, same
+// per-cell arithmetic, bit-identical to three single steps.  partials3 receives step t+3's sums.
+struct Window {
+  float trail[3][4];  // oldest row: the three planes moving in sweep direction (no shift, from west, from east)
+  float mid[6][4];    // middle row: planes 0,1,3 and the three that become `trail`
+  uint32_t m_mid;     // obstacle flags of the middle row's cells
+};
+
+// gather of one step from a window + the newest row `top` (see d2q9_step2), direction-dependent plane roles
+__device__ __forceinline__ void window_gather(const Window &w, const float (&top)[9][4], bool up, float (&g)[9][4]) {
+  float a1[4], a2[4], b1[4], b2[4], t[4];
+  shift_from_west(w.mid[1], 0.f, g[1]);
+  shift_from_east(w.mid[2], 0.f, g[3]);
+  shift_from_west(w.trail[1], 0.f, a1);
+  shift_from_east(w.trail[2], 0.f, a2);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[8][v] : top[5][v];
+  shift_from_west(t, 0.f, b1);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[7][v] : top[6][v];
+  shift_from_east(t, 0.f, b2);
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const float b0 = up ? top[4][v] : top[2][v];
+    g[0][v] = w.mid[0][v];
+    g[2][v] = up ? w.trail[0][v] : b0;
+    g[4][v] = up ? b0 : w.trail[0][v];
+    g[5][v] = up ? a1[v] : b1[v];
+    g[8][v] = up ? b1[v] : a1[v];
+    g[6][v] = up ? a2[v] : b2[v];
+    g[7][v] = up ? b2[v] : a2[v];
+  }
+}
+
+__device__ __forceinline__ void window_rotate(Window &w, const float (&top)[9][4], uint32_t m_top, bool up) {
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    w.trail[0][v] = w.mid[3][v]; w.trail[1][v] = w.mid[4][v]; w.trail[2][v] = w.mid[5][v];
+    w.mid[0][v] = top[0][v]; w.mid[1][v] = top[1][v]; w.mid[2][v] = top[3][v];
+    w.mid[3][v] = up ? top[2][v] : top[4][v];
+    w.mid[4][v] = up ? top[5][v] : top[8][v];
+    w.mid[5][v] = up ? top[6][v] : top[7][v];
+  }
+  w.m_mid = m_top;
+}
+
+template <bool NT, int NTL = 0>
+__global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *partials3) {
+  const int lane = threadIdx.x;
+  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
+  if (slot >= a.units_per_band) return;
+  const int unit = band * a.units_per_band + slot;
+  const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
+  const int ys = a.chunk_start[chunk];
+  const int ye = a.chunk_start[chunk + 1];
+  if (ys >= ye || chunk == a.skip_chunk) {
+    if (lane == 0) a.partials1[unit] = a.partials2[unit] = partials3[unit] = 0.f;
+    return;
+  }
+  const int q4 = a.nx >> 2;
+  const int qcol = strip * a.lanes_out + lane - 2;  // lanes 0,1 and 62,63 are halo lanes
+  const bool owner = (lane >= 2) && (lane < 2 + a.lanes_out) && (qcol < q4);
+  int qw = qcol % q4;
+  if (qw < 0) qw += q4;
+  const int xcol = qw * 4;
+  const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
+  const int xhalo_e = (xcol + 4 >= a.nx) ? 0 : xcol + 4;
+  const size_t ps = a.plane_stride;
+  auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
+
+  const bool up = __builtin_amdgcn_readfirstlane((int)((chunk & 1) == 0)) != 0;
+  const int n = ye - ys;
+  const int d = up ? 1 : -1;
+  const int r0 = up ? ys - 2 : ye + 1;  // row of the k-th first-level row: r0 + k*d, k = 0 .. n+3
+
+  float sum1 = 0.f, sum2 = 0.f, sum3 = 0.f;
+  Window w1, w2;
+  float top1[9][4], top2[9][4];
+  RowLoads inA, inB;
+  issue_row_loads<NTL == 1>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, inA);
+  issue_row_loads<NTL == 1>(a, wrap(r0 + d), xcol, xhalo_w, xhalo_e, lane, inB);
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) w1.trail[k][v] = w2.trail[k][v] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) w1.mid[k][v] = w2.mid[k][v] = 0.f;
+  }
+  w1.m_mid = w2.m_mid = 0;
+
+  auto iterate = [&](int k, RowLoads &in) {
+    // level 1: state after step t+1 on row r0 + k*d (rows k = 2 .. n+1 are this chunk's own)
+    const int row1 = wrap(r0 + k * d);
+    const float t1 = first_step_row(a, in, row1, top1);
+    const uint32_t m1 = in.m;
+    if (owner && k >= 2 && k <= n + 1) sum1 += t1;
+    if (k + 2 <= n + 3) {
+      // source rows shared with the neighbouring chunk (its own sweep reads them too) stay cacheable
+      if (NTL == 2 && k + 2 >= 4 && k + 2 <= n - 1) issue_row_loads<true>(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      else issue_row_loads<NTL == 1>(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    }
+    // level 2: state after step t+2 on the middle row of window 1 (row r0 + (k-1)*d), from the third iteration on
+    uint32_t m2 = 0;
+    if (k >= 2) {
+      const int row2 = wrap(r0 + (k - 1) * d);
+      float g[9][4];
+      window_gather(w1, top1, up, g);
+      m2 = w1.m_mid;
+      const float t2 = collide4(g, m2, a.omega, row2 == a.accel_row || row2 == a.accel_row_b, a.aw1, a.aw2, top2);
+      if (owner && k >= 3 && k <= n + 2) sum2 += t2;
+    }
+    // level 3: step t+3 on the middle row of window 2 (row r0 + (k-2)*d), from the fifth iteration on
+    if (k >= 4) {
+      const int y = r0 + (k - 2) * d;
+      float g[9][4], o[9][4];
+      window_gather(w2, top2, up, g);
+      const float t3 = collide4(g, w2.m_mid, a.omega, (y == a.accel_row || y == a.accel_row_b) && a.accel_next, a.aw1, a.aw2, o);
+      if (owner) {
+        sum3 += t3;
+        float *dp = a.dst + (size_t)y * a.row_stride + xcol;
+#pragma unroll
+        for (int kk = 0; kk < 9; kk++) store4<NT>(dp + kk * ps, o[kk][0], o[kk][1], o[kk][2], o[kk][3]);
+      }
+    }
+    if (k >= 2) window_rotate(w2, top2, m2, up);
+    window_rotate(w1, top1, m1, up);
+  };
+  for (int k = 0; k <= n + 3; k += 2) {
+    iterate(k, inA);
+    if (k + 1 <= n + 3) iterate(k + 1, inB);
+  }
+  sum1 = wave_sum(sum1);
+  sum2 = wave_sum(sum2);
+  sum3 = wave_sum(sum3);
+  if (lane == 0) {
+    a.partials1[unit] = sum1;
+    a.partials2[unit] = sum2;
+    partials3[unit] = sum3;
   }
 }
 

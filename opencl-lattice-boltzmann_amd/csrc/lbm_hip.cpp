@@ -116,6 +116,7 @@ struct Slab {
   int ext_rows = 0;       // rows stored = rows + 2*row0
   int accel_own = -1;     // stored-row index of global row ny-2 if this slab owns it, else -1
   int accel_ext = -1;     // same, also when the row is one of the stored halo rows
+  int accel_ext_b = -1;   // a second stored copy (only a slab that is its own ring neighbour has one)
   size_t plane_stride = 0;  // floats between the 9 plane-rows of a grid row (padded row length)
   size_t row_stride = 0;    // floats between grid rows = 9*plane_stride (+ pad)
   float *cells[2] = {nullptr, nullptr};  // [ext_rows][9][plane_stride]
@@ -125,6 +126,7 @@ struct Slab {
   int nb_total = 0;              // slot stride of the ring
   int strips = 0, lanes_out = 0;  // x decomposition of d2q9_step2
   FuseGeom f_main, f_edge;        // whole slab (one slab) or interior chunks; the two edge chunks
+  FuseGeom f3_main;               // schedule of d2q9_step3 (one slab): 1 wave per SIMD, longer chunks
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
   int m_tx = 32, m_ty = 16;          // its tile size (chosen by how many tiles the slab gives)
@@ -152,7 +154,8 @@ struct lbm_ctx {
   bool halo_mode = false;   // slabs carry halo rows and exchange them (more than one slab, or forced for tests)
   int rows_min = 0;         // smallest slab of the partition (ny / nslabs): every rank takes the size-dependent
                             // decisions (kernel, halo depth, schedule) from it, so that all ranks take the same ones
-  int halo_depth = 2;       // rows exchanged per side and launch set: 2 (two-step kernel) or 8 (LDS multi-step kernel, small slabs)
+  int halo_depth = 3;       // rows exchanged per side and launch set: 3 (three-step kernel; 2 for very thin slabs) or 8
+                            // (LDS multi-step kernel, small slabs)
   int rank = 0;
   int cur = 0;              // index of the grid holding the current state
   int steps_done = 0;
@@ -213,13 +216,24 @@ bool fuse_possible(const lbm_ctx *c) {
   if (!c->vec4 || c->p.nx < 256) return false;
   return c->rows_min >= 8;
 }
-bool fuse_effective(const lbm_ctx *c) {
-  if (!fuse_possible(c)) return false;
-  if (c->fuse >= 0) return c->fuse != 0;
-  // auto: from 768x768 up it beats one launch per step (profiles/r01_kernel_choice.txt); smaller grids have too
-  // few strip x chunk units to fill 2048 wave slots
-  return (long)c->p.nx * c->rows_min > 540L * 1024;
+// 0 = one launch per step, 2 = d2q9_step2, 3 = d2q9_step3 (falls back to 2 for the last steps of a run and
+// where the halo rows are fewer than 3)
+int fuse_level(const lbm_ctx *c) {
+  if (!fuse_possible(c)) return 0;
+  int lvl;
+  if (c->fuse >= 0) {
+    lvl = c->fuse == 0 ? 0 : (c->fuse == 3 ? 3 : 2);
+  } else {
+    // auto (same-box A/B, tools/ab_fuse3.py): below ~768x768 one launch per step / the LDS kernel win; two steps
+    // per launch up to 1536x1024 (127 vs 124 GLUPS); three steps per launch from 2048x1024 on (137 vs 124,
+    // 8192x8192: 188 vs 152)
+    const long cells = (long)c->p.nx * c->rows_min;
+    lvl = cells >= (2L << 20) ? 3 : (cells > 540L * 1024 ? 2 : 0);
+  }
+  if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
+  return lvl;
 }
+bool fuse_effective(const lbm_ctx *c) { return fuse_level(c) != 0; }
 
 // LDS multi-step kernel: one slab holding the whole periodic grid; worth it only while the grid is launch-bound
 int multistep_effective(const lbm_ctx *c) {
@@ -239,10 +253,10 @@ int multistep_effective(const lbm_ctx *c) {
 // leave the chip partly idle during the last round of units (17 % of the launch with 32-row chunks on
 // 8192x8192).  The schedule therefore tapers: every band (the share of one XCD) starts with chunks of
 // `cmax` rows and ends with ever shorter ones (guided self-scheduling), down to `cmin`.
-int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g) {
+int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g, int waves_per_simd = 2) {
   const int rows = r1 - r0;
   g.nbands = (allow_bands && rows >= 8 * 4 * cmin) ? 8 : 1;
-  const int waves_resident = 256 * 8;  // CUs x waves per CU at 2 waves/SIMD
+  const int waves_resident = 256 * 4 * waves_per_simd;  // CUs x SIMDs x waves per SIMD the kernel's registers allow
   const double slots = std::max(1.0, (double)waves_resident / g.nbands / s.strips);  // concurrent chunks per band
   std::vector<int> starts;
   int chunks_per_band = 0;
@@ -334,6 +348,11 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     int cmax = c->chunk_rows > 0 ? c->chunk_rows : (big ? 6 : 8);
     cmax = std::max(2, std::min(cmax, s.rows));
     const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), cmax));
+    // d2q9_step3: six redundant intermediate rows per chunk and one wave per SIMD -> long chunks (tools/ab_fuse3.py:
+    // 8192x8192 16/6: 178, 32/6: 186, 64/8: 188 GLUPS; 8192x1024: 32/6 159, 64/8 156)
+    int c3max = c->chunk_rows > 0 ? c->chunk_rows : (c->rows_min >= 2048 ? 64 : 32);
+    c3max = std::max(4, std::min(c3max, s.rows));
+    const int c3min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (c->rows_min >= 2048 ? 8 : 6), c3max));
     if (multi) {
       // the two edge chunks hold the rows the neighbours need (2 each); the interior is everything else
       // (edge chunks are as short as the exchange allows — 2 rows when the halo depth is 2: an edge unit is one
@@ -353,13 +372,16 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       const int i0 = s.row0 + s.edge_rows, i1 = s.row0 + s.rows - s.edge_rows;
       if (i1 > i0) {
         if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main)) return rc;
+        if (int rc = fuse_schedule(s, i0, i1, c3max, c3min, true, s.f3_main, 1)) return rc;
       } else {
-        s.f_main.units = 0;
+        s.f_main.units = s.f3_main.units = 0;
       }
-      s.nb_total = std::max(s.nb_total, s.f_main.units + e.units);
+      s.nb_total = std::max(s.nb_total, std::max(s.f_main.units, s.f3_main.units) + e.units);
     } else {
       if (int rc = fuse_schedule(s, 0, s.rows, cmax, cmin, true, s.f_main)) return rc;
       s.nb_total = std::max(s.nb_total, s.f_main.units);
+      if (int rc = fuse_schedule(s, 0, s.rows, c3max, c3min, true, s.f3_main, 1)) return rc;
+      s.nb_total = std::max(s.nb_total, s.f3_main.units);
     }
   }
   return LBM_OK;
@@ -443,11 +465,20 @@ Step2Args base_args2(const lbm_ctx *c, const Slab &s, int src, bool accel_next, 
   a.units_per_band = g.units_per_band;
   a.skip_chunk = -1;
   a.accel_row = s.accel_ext;
+  a.accel_row_b = s.accel_ext_b;
   a.accel_next = accel_next ? 1 : 0;
   a.omega = c->p.omega;
   a.aw1 = c->p.density * c->p.accel / 9.0f;
   a.aw2 = c->p.density * c->p.accel / 36.0f;
   return a;
+}
+
+void launch_step3(const lbm_ctx *c, const Step2Args &a, float *partials3, int units, hipStream_t st) {
+  const int ntl = c->nt_loads >= 0 ? c->nt_loads : 2;
+  const dim3 grid(units), block(64);
+  if (ntl == 2) hipLaunchKernelGGL((d2q9_step3<true, 2>), grid, block, 0, st, a, partials3);
+  else if (ntl == 1) hipLaunchKernelGGL((d2q9_step3<true, 1>), grid, block, 0, st, a, partials3);
+  else hipLaunchKernelGGL((d2q9_step3<true, 0>), grid, block, 0, st, a, partials3);
 }
 
 MultiArgs base_args_multi(const lbm_ctx *c, const Slab &s, int src, int T, bool accel_next) {
@@ -537,7 +568,8 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
   if (timed && ms) *ms = 0.0;
   if (nsteps == 0) return LBM_OK;
   const bool multi = c->halo_mode;
-  const bool fuse = fuse_effective(c);
+  const int fuse_lvl = fuse_level(c);
+  const bool fuse = fuse_lvl != 0;
   const float aw1 = c->p.density * c->p.accel / 9.0f, aw2 = c->p.density * c->p.accel / 36.0f;
   const int nx = c->p.nx;
 
@@ -574,7 +606,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     }
 
   int batch_first = c->steps_done;
-  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3 };
+  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4 };
   int batch_kind = KIND_NONE;  // launch kind of the steps buffered in the ring (their slot occupancy differs)
   int last_q = 1;
   const int multi_T = multistep_effective(c);
@@ -587,6 +619,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       if (multi) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[last_q], 0));
       int used = s.nb_main + s.nb_edge;
       if (batch_kind == KIND_FUSED2) used = s.f_main.units + (multi ? s.f_edge.units : 0);
+      if (batch_kind == KIND_FUSED3) used = s.f3_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_MULTI) used = s.m_tiles_x * s.m_tiles_y;
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
@@ -610,6 +643,9 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     if (multi_T > 0) {
       kind = KIND_MULTI;
       adv = std::min(multi_T, nsteps - i);
+    } else if (fuse_lvl == 3 && nsteps - i >= 3) {
+      kind = KIND_FUSED3;
+      adv = 3;
     } else if (fuse && nsteps - i >= 2) {
       kind = KIND_FUSED2;
       adv = 2;
@@ -629,6 +665,11 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           a.partials = slot1;
           a.ty_begin = 0; a.ty_split = s.m_tiles_y; a.ty_begin2 = 0;
           launch_multi(s, a, s.m_tiles_y, s.s_main);
+        } else if (kind == KIND_FUSED3) {
+          Step2Args a = base_args2(c, s, src, !last, s.f3_main);
+          a.partials1 = slot1;
+          a.partials2 = slot2;
+          launch_step3(c, a, slot2 + s.nb_total, s.f3_main.units, s.s_main);
         } else if (kind == KIND_FUSED2) {
           Step2Args a = base_args2(c, s, src, !last, s.f_main);
           a.partials1 = slot1;
@@ -664,6 +705,21 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           mm.partials = slot1;
           mm.ty_begin = 1; mm.ty_split = int_trows; mm.ty_begin2 = 0;
           launch_multi(s, mm, int_trows, s.s_main);
+          HIP_TRY(hipGetLastError());
+        }
+      } else if (kind == KIND_FUSED3) {
+        float *slot3 = slot2 + s.nb_total;
+        Step2Args e = base_args2(c, s, src, !last, s.f_edge);
+        e.skip_chunk = 1;  // chunk table {bottom edge, (interior), top edge}
+        e.partials1 = slot1 + s.f3_main.units;
+        e.partials2 = slot2 + s.f3_main.units;
+        launch_step3(c, e, slot3 + s.f3_main.units, s.f_edge.units, s.s_edge);
+        HIP_TRY(hipGetLastError());
+        if (s.f3_main.units > 0) {
+          Step2Args m = base_args2(c, s, src, !last, s.f3_main);
+          m.partials1 = slot1;
+          m.partials2 = slot2;
+          launch_step3(c, m, slot3, s.f3_main.units, s.s_main);
           HIP_TRY(hipGetLastError());
         }
       } else if (kind == KIND_FUSED2) {
@@ -750,6 +806,7 @@ void free_slab(Slab &s) {
   if (s.fin_partials) hipFree(s.fin_partials);
   if (s.f_main.chunk_start) hipFree(s.f_main.chunk_start);
   if (s.f_edge.chunk_start) hipFree(s.f_edge.chunk_start);
+  if (s.f3_main.chunk_start) hipFree(s.f3_main.chunk_start);
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
@@ -810,12 +867,13 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
     HIP_TRY(hipMemcpy(s.mask, m.data(), n_ext, hipMemcpyHostToDevice));
   }
   // the accelerated row ny-2 (kernels.cl:18) in stored-row coordinates
-  s.accel_own = s.accel_ext = -1;
+  s.accel_own = s.accel_ext = s.accel_ext_b = -1;
   for (int e = 0; e < s.ext_rows; e++) {
     const int gy = ((s.y0 - s.row0 + e) % ny + ny) % ny;
     if (gy != ny - 2) continue;
     if (e >= s.row0 && e < s.row0 + s.rows) s.accel_own = e;
-    if (s.accel_ext < 0 || s.accel_own == e) s.accel_ext = e;  // (stored rows repeat only if ext_rows > ny: excluded at creation)
+    if (s.accel_ext < 0) s.accel_ext = e;
+    else s.accel_ext_b = e;
   }
   if (dev_alloc(&s.av_sum, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
   s.fin_blocks = std::max(1, std::min(div_up((long)nx * s.rows, kBlock), 2048));
@@ -895,7 +953,8 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     const int rows_min = params->ny / nslabs_global;
     c->rows_min = rows_min;
     const bool small = (long)params->nx * rows_min <= 540L * 1024;
-    c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : 2;
+    // ... and big slabs depth 3, what the three-steps-per-launch kernel needs
+    c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : (rows_min >= 6 ? 3 : 2);
     if (const char *hd = getenv("LBM_HALO_DEPTH")) c->halo_depth = std::max(2, std::min(kMultiMaxT, atoi(hd)));
     if (rows_min < 2 * c->halo_depth) c->halo_depth = 2;
   }
@@ -1210,7 +1269,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   if (!strcmp(key, "variant")) *value = effective_mode(c) + 1;
   else if (!strcmp(key, "grid_blocks")) *value = c->slabs.empty() ? 0 : c->slabs[0].nb_main;
   else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
-  else if (!strcmp(key, "fuse")) *value = fuse_effective(c);
+  else if (!strcmp(key, "fuse")) *value = fuse_level(c) == 3 ? 3 : (fuse_level(c) ? 1 : 0);
   else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_main.units + c->slabs[0].f_edge.units;

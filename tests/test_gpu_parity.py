@@ -22,6 +22,7 @@ RTOL_AV = 1e-4
 # two-steps-per-launch kernel from ~1024x768, one step per launch in between and as the odd last step)
 SINGLE = {"fuse": 0, "multistep": 0}
 FUSED2 = {"fuse": 1, "multistep": 0}
+FUSED3 = {"fuse": 3, "multistep": 0}
 
 
 def max_rel(a, b):
@@ -145,7 +146,7 @@ def test_lds_multistep_equals_single_steps(lbm, oracle_f32_omp, nx, ny, T, nstep
 def test_default_kernel_choice_by_grid_size(lbm):
     """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel for bandwidth-bound ones"""
     expect = {(128, 128): (8, 0), (256, 256): (8, 0), (512, 512): (8, 0), (1024, 512): (8, 0), (768, 768): (0, 1),
-              (1024, 1024): (0, 1), (128, 8192): (0, 0)}
+              (1024, 1024): (0, 1), (1536, 1024): (0, 1), (2048, 1024): (0, 3), (4096, 2048): (0, 3), (128, 8192): (0, 0)}
     for (nx, ny), (ms, fuse) in expect.items():
         ob = np.zeros((ny, nx), np.int32)
         with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
@@ -271,11 +272,12 @@ def test_final_state_and_reynolds(lbm, oracle_f32):
 # ---- row partition on one GPU (several slabs on device 0, halos by device-to-device copies) ----------
 
 @pytest.mark.parametrize("nslabs,ny", [(2, 50), (3, 50), (8, 50), (2, 16), (4, 67), (5, 128), (2, 260)])
-@pytest.mark.parametrize("mode", ["single", "fused2", "multi8", "multi3", "auto"])
+@pytest.mark.parametrize("mode", ["single", "fused2", "fused3", "multi8", "multi3", "auto"])
 def test_row_slabs_equal_single_slab(lbm, nslabs, ny, mode):
     """several slabs on one GPU (halo rows exchanged by device-to-device copies) against one slab, with one,
     two and up to eight timesteps per launch set (halo depth 2 or 8); 37 steps = full launch sets + a remainder"""
-    opts = {"single": SINGLE, "fused2": FUSED2, "multi8": {"multistep": 8}, "multi3": {"multistep": 3}, "auto": {}}[mode]
+    opts = {"single": SINGLE, "fused2": FUSED2, "fused3": FUSED3, "multi8": {"multistep": 8}, "multi3": {"multistep": 3},
+            "auto": {}}[mode]
     rng = np.random.default_rng(5)
     nx, nsteps = 256, 37
     ob, cells0 = random_case(rng, nx, ny)
@@ -307,8 +309,9 @@ def test_row_slabs_large_fused(lbm):
     ob, cells0 = random_case(rng, nx, ny, blocked=0.02)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
-    many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, FUSED2, devices=[0, 0, 0, 0])
-    assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
+    for opts in (FUSED2, FUSED3, {}):  # {} = auto: three steps per launch on 2048x128 slabs? no - 8 steps on LDS tiles
+        many, av_many = run_gpu(lbm, p, ob, cells0, nsteps, opts, devices=[0, 0, 0, 0])
+        assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
 
 
 def test_row_slabs_split_runs_and_shipped_geometry(lbm, oracle_f32_omp):
@@ -501,7 +504,23 @@ def test_odd_large_shapes_all_kernels_agree(lbm, nx, ny):
     nsteps = 7
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     base, av_base = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
-    for opts, kw in ((FUSED2, {}), ({"multistep": 4}, {}), (FUSED2, {"devices": [0, 0, 0, 0]}), ({}, {"devices": [0, 0]})):
+    for opts, kw in ((FUSED2, {}), (FUSED3, {}), ({"multistep": 4}, {}), (FUSED2, {"devices": [0, 0, 0, 0]}),
+                     (FUSED3, {"devices": [0, 0, 0]}), ({}, {"devices": [0, 0]})):
         got, av = run_gpu(lbm, p, ob, cells0, nsteps, opts, **kw)
         assert np.array_equal(got, base), (opts, kw)
         assert max_rel(av, av_base) < 2e-6
+
+
+@pytest.mark.parametrize("nx,ny,chunk", [(256, 8, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (2048, 16, 16), (260, 33, 4),
+                                         (8192, 24, 8)])
+@pytest.mark.parametrize("nsteps", [3, 4, 5, 10])
+def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps):
+    """d2q9_step3 (three timesteps per launch, two register windows): bit-identical to single steps; step counts
+    that are no multiple of three finish with the two-step / single-step kernels"""
+    rng = np.random.default_rng(3 * nx + ny + nsteps)
+    ob, cells0 = random_case(rng, nx, ny)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    got, av = run_gpu(lbm, p, ob, cells0, nsteps, {"multistep": 0, "fuse": 3, "chunk_rows": chunk})
+    assert np.array_equal(got, single)
+    assert max_rel(av, av_single) < 2e-6

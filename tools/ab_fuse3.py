@@ -1,0 +1,15 @@
+import sys
+import numpy as np
+sys.path.insert(0, '.')
+import lbm_amd
+for (nx, ny, steps) in [(1024, 1024, 1920), (1536, 1024, 1920), (2048, 1024, 1920), (2048, 1536, 960), (2048, 2048, 960), (8192, 1024, 480), (8192, 2048, 240)]:
+    ob = np.zeros((ny, nx), np.int32); ob[0, :] = ob[-1, :] = 1; ob[:, 0] = ob[:, -1] = 1
+    p = lbm_amd.make_params(nx, ny, 100000, obstacles=ob)
+    with lbm_amd.LBM(p, ob) as sim:
+        sim.set_option("multistep", 0)
+        for rnd in range(2):
+            for (fuse, chunk, cmin) in [(1, 0, 0), (3, 32, 6), (3, 64, 8)]:
+                sim.set_option("fuse", fuse); sim.set_option("chunk_min", cmin); sim.set_option("chunk_rows", chunk)
+                sim.upload(None); sim.run(24)
+                best = min(sim.run_timed(steps) for _ in range(2))
+                print("%5dx%-5d fuse=%d chunk=%-2d min=%-2d us/step %9.3f MLUPS %8.0f" % (nx, ny, fuse, chunk, cmin, best / steps * 1e3, nx * ny * steps / best / 1e3), flush=True)
