@@ -180,7 +180,7 @@ def main():
         sim = lbm_amd.LBM(params, obstacles)
     if args.fuse >= 0:
         sim.set_option("fuse", args.fuse)
-    fused = bool(sim.get_option("fuse"))
+    fused = {0: 0, 1: 2, 3: 3}[sim.get_option("fuse")]   # timesteps per launch of the dominant kernel (0: one)
     sim.upload(None)  # uniform rest state, built on the device
     y0, y1 = sim.row_range()
 
@@ -208,7 +208,7 @@ def main():
         lups = nx * ny * args.steps / wall
         rows_local = y1 - y0
         # the dominant kernel advances `steps_per_launch` timesteps of the rank's slab per launch
-        steps_per_launch = 2 if fused else 1
+        steps_per_launch = fused if fused else 1
         launches = args.steps // steps_per_launch + args.steps % steps_per_launch
         launch_s = loop_ms * 1e-3 / launches
         alg_bytes = BYTES_PER_LU * nx * rows_local * steps_per_launch
@@ -225,7 +225,8 @@ def main():
                 "omega": 1.85, "accel": args.accel, "density": 0.1},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "d2q9_step2 (two timesteps per launch)" if fused else "d2q9_step",
+                         "kernel": {0: "d2q9_step", 2: "d2q9_step2 (two timesteps per launch)",
+                                    3: "d2q9_step3 (three timesteps per launch)"}[fused],
                          "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "result_ok": ok,
@@ -247,9 +248,9 @@ def main():
         except lbm_amd.LBMError:
             pass
         if fused:
-            out["roofline"]["note"] = ("frac uses the ALGORITHMIC 72 B per lattice update; the two-step kernel keeps the "
-                                       "intermediate state in registers and really moves ~43 B per update (traffic), so frac "
-                                       "can exceed 1 while traffic_frac is the share of the 8 TB/s peak actually used")
+            out["roofline"]["note"] = ("frac uses the ALGORITHMIC 72 B per lattice update; the multi-step kernels keep the "
+                                       "intermediate states in registers and really move far fewer bytes per update (traffic), "
+                                       "so frac can exceed 1 while traffic_frac is the share of the 8 TB/s peak actually used")
     sim.close()
 
     if world == 1 and rank == 0:

@@ -8,15 +8,15 @@ iv = {"interior": [], "edge": [], "rccl": []}
 for r in rows:
     name, st, en = r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
-    if "d2q9_step2" in name:
+    if "d2q9_step2" in name or "d2q9_step3" in name:
         iv["pending"] = iv.get("pending", []) + [(st, en, grid)]
     elif "nccl" in name.lower() or "rccl" in name.lower():
         iv["rccl"].append((st, en))
-# the edge launch has 3*strips units (a few thousand threads), the interior launch many more
+# the edge launch has 3*strips units (a few thousand threads), the interior launches many more
 p = iv.pop("pending")
-gmax = max(g for _, _, g in p)
+gmin = min(g for _, _, g in p)
 for st, en, g in p:
-    (iv["interior"] if g > gmax // 2 else iv["edge"]).append((st, en))
+    (iv["edge"] if g <= 2 * gmin else iv["interior"]).append((st, en))
 def overlap(a, others):
     tot = 0
     for (s, e) in others:

@@ -58,11 +58,12 @@ with open(os.path.join(G, "prof_%s_stats" % tag, "stats_kernel_stats.csv")) as f
             avg_ns = float(r["AverageNs"])
             lines.append("kernel-trace: %s calls=%s average=%.1f us" % (r["Name"], r["Calls"], avg_ns / 1e3))
 nx, ny = (int(v) for v in workload.split("x"))
-fused = "step2" in step_kernel
-alg = 72.0 * nx * ny * (2 if fused else 1)
-lines += ["", "dominant kernel: %s (%d timestep(s) per launch)" % (step_kernel, 2 if fused else 1), "step kernel, %s: FETCH_SIZE %.6g KiB (x2 on gfx950), WRITE_SIZE %.6g KiB" % (workload, step_fetch, step_write),
+per_launch = 3 if "step3" in step_kernel else (2 if "step2" in step_kernel else 1)
+fused = per_launch > 1
+alg = 72.0 * nx * ny * per_launch
+lines += ["", "dominant kernel: %s (%d timestep(s) per launch)" % (step_kernel, per_launch), "step kernel, %s: FETCH_SIZE %.6g KiB (x2 on gfx950), WRITE_SIZE %.6g KiB" % (workload, step_fetch, step_write),
           "HBM bytes per launch = (2*FETCH + WRITE)*1024 = %.6g  (reads %.6g, writes %.6g)" % (hbm, 2 * step_fetch * 1024, step_write * 1024),
-          "algorithmic bytes per launch = 72 B x %d cells x %d step(s) = %.6g ; traffic / algorithmic = %.4f" % (nx * ny, 2 if fused else 1, alg, hbm / alg),
+          "algorithmic bytes per launch = 72 B x %d cells x %d step(s) = %.6g ; traffic / algorithmic = %.4f" % (nx * ny, per_launch, alg, hbm / alg),
           "traffic rate = %.1f GB/s" % (hbm / avg_ns),
           "achieved (algorithmic bytes / average kernel time) = %.1f GB/s" % (alg / avg_ns)]
 open(os.path.join(P, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
