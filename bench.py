@@ -236,8 +236,7 @@ def main():
         if os.path.exists(tp) and world == 1:
             with open(tp) as f:
                 tj = json.load(f)
-            key = "%dx%d" % (nx, ny)
-            key += "/fused" if fused else "/single"
+            key = "%dx%d/step%d" % (nx, ny, steps_per_launch)
             if key in tj:
                 out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_frac"] = round(tj[key]["hbm_bytes_per_launch"] / launch_s / 1e9 / HBM_PEAK_GBPS, 4)

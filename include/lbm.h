@@ -127,8 +127,12 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "variant"      how a thread gets its x-1/x+1 neighbours: 0 = auto, 1 = scalar L1 loads,
  *                  2 = unaligned 16-byte loads, 3 = wave64 DPP shifts, 4 = LDS-staged row with halo
  *   "fuse"         1 (or 2) = advance two timesteps per launch (intermediate state kept in registers, half
- *                  the HBM traffic), 3 = three timesteps per launch (two register windows, a third of the
- *                  traffic), 0 = one launch per step, -1 = auto (by grid size).
+ *                  the HBM traffic), 3 = three timesteps per launch (two windows of intermediate rows, a third
+ *                  of the traffic), 0 = one launch per step, -1 = auto (by grid size).
+ *   "windows"      where the three-step kernel keeps its two windows: 1 = LDS (two waves per SIMD), 0 = registers
+ *                  (one wave per SIMD), -1 = auto (1)
+ *   "load_bufs"    row-sets of source loads the three-step kernel keeps in flight: 1 or 2, 0 = auto
+ *   "sched_waves"  waves per SIMD the three-step kernel's chunk schedule plans for: 1 or 2, 0 = auto
  *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
  *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)

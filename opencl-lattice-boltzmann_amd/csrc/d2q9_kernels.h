@@ -154,6 +154,8 @@ __device__ __forceinline__ void block_store_partial(float v, float *partials) {
 }
 
 // gathered distributions g[k][v] -> collided cell values o[k][v]; returns the sum of |j|/rho of the 4 cells
+// (tried and rejected, tools/ab_step3.py: bounce-back as a wave-uniform fix-up branch after an obstacle-free
+// collision — 14 % slower in d2q9_step3, 4-40 % slower in d2q9_step2: both g and o stay live across the branch)
 __device__ __forceinline__ float collide4(const float (&g)[9][4], uint32_t m, float omega, bool accel, float aw1, float aw2,
                                           float (&o)[9][4]) {
   float tot = 0.f;
@@ -619,8 +621,68 @@ __device__ __forceinline__ void window_rotate(Window &w, const float (&top)[9][4
   w.m_mid = m_top;
 }
 
-template <bool NT, int NTL = 0>
+// LDS-resident form of a Window: a workgroup is ONE wave, so its LDS is private to the wave and needs no barrier
+// (a wave's LDS operations complete in order).  Slot s of a window holds one float4 per lane at (s*64 + lane);
+// slots 0..2 = planes 0,1,3 of the middle row, slots 3+3p .. 5+3p = the sweep-direction planes of the rows of
+// parity p (written in iteration k, read as `trail` in iteration k+2).  Moving both windows (72 registers) to
+// LDS brings the kernel under 256 registers: two waves per SIMD instead of one.
+constexpr int kWinSlots = 9;
+__device__ __forceinline__ void lds_put(v4f *w, int slot, const float (&p)[4]) {
+  v4f v; v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
+  w[slot * 64] = v;
+}
+__device__ __forceinline__ void lds_get(const v4f *w, int slot, float (&p)[4]) {
+  const v4f v = w[slot * 64];
+  p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+}
+
+// gather from an LDS window (w already offset by the lane) + the newest row `top`, then store `top` as the
+// window's new middle row: the LDS counterpart of window_gather followed by window_rotate
+__device__ __forceinline__ void lds_window_gather(const v4f *w, int par, const float (&top)[9][4], bool up, float (&g)[9][4]) {
+  float a1[4], a2[4], b1[4], b2[4], t[4], tr0[4];
+  lds_get(w, 1, t); shift_from_west(t, 0.f, g[1]);
+  lds_get(w, 2, t); shift_from_east(t, 0.f, g[3]);
+  lds_get(w, 0, g[0]);
+  lds_get(w, 3 + 3 * par, tr0);
+  lds_get(w, 4 + 3 * par, t); shift_from_west(t, 0.f, a1);
+  lds_get(w, 5 + 3 * par, t); shift_from_east(t, 0.f, a2);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[8][v] : top[5][v];
+  shift_from_west(t, 0.f, b1);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[7][v] : top[6][v];
+  shift_from_east(t, 0.f, b2);
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const float b0 = up ? top[4][v] : top[2][v];
+    g[2][v] = up ? tr0[v] : b0;
+    g[4][v] = up ? b0 : tr0[v];
+    g[5][v] = up ? a1[v] : b1[v];
+    g[8][v] = up ? b1[v] : a1[v];
+    g[6][v] = up ? a2[v] : b2[v];
+    g[7][v] = up ? b2[v] : a2[v];
+  }
+}
+
+__device__ __forceinline__ void lds_window_put(v4f *w, int par, const float (&top)[9][4], bool up) {
+  float t[4];
+  lds_put(w, 0, top[0]); lds_put(w, 1, top[1]); lds_put(w, 2, top[3]);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[2][v] : top[4][v];
+  lds_put(w, 3 + 3 * par, t);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[5][v] : top[8][v];
+  lds_put(w, 4 + 3 * par, t);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[6][v] : top[7][v];
+  lds_put(w, 5 + 3 * par, t);
+}
+
+// WLDS: the two windows live in LDS (two waves per SIMD) instead of registers (one wave per SIMD).
+// NBUF: row-sets of source loads in flight (2 = ping-pong as in d2q9_step2, 1 = the next row only).
+template <bool NT, int NTL = 0, bool WLDS = false, int NBUF = 2>
 __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *partials3) {
+  __shared__ v4f win[WLDS ? 2 * kWinSlots * 64 : 1];
   const int lane = threadIdx.x;
   const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
   if (slot >= a.units_per_band) return;
@@ -650,46 +712,56 @@ __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *parti
 
   float sum1 = 0.f, sum2 = 0.f, sum3 = 0.f;
   Window w1, w2;
+  v4f *const lw1 = win + lane, *const lw2 = win + (WLDS ? kWinSlots * 64 : 0) + lane;
+  uint32_t m_mid1 = 0, m_mid2 = 0;
   float top1[9][4], top2[9][4];
   RowLoads inA, inB;
   issue_row_loads<NTL == 1>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, inA);
-  issue_row_loads<NTL == 1>(a, wrap(r0 + d), xcol, xhalo_w, xhalo_e, lane, inB);
+  if (NBUF == 2) issue_row_loads<NTL == 1>(a, wrap(r0 + d), xcol, xhalo_w, xhalo_e, lane, inB);
+  if (!WLDS) {
 #pragma unroll
-  for (int v = 0; v < 4; v++) {
+    for (int v = 0; v < 4; v++) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) w1.trail[k][v] = w2.trail[k][v] = 0.f;
+      for (int k = 0; k < 3; k++) w1.trail[k][v] = w2.trail[k][v] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 6; k++) w1.mid[k][v] = w2.mid[k][v] = 0.f;
+      for (int k = 0; k < 6; k++) w1.mid[k][v] = w2.mid[k][v] = 0.f;
+    }
   }
-  w1.m_mid = w2.m_mid = 0;
 
-  auto iterate = [&](int k, RowLoads &in) {
+  auto iterate = [&](int k, RowLoads &in, const bool up) __attribute__((always_inline)) {
+    const int par = k & 1;
     // level 1: state after step t+1 on row r0 + k*d (rows k = 2 .. n+1 are this chunk's own)
     const int row1 = wrap(r0 + k * d);
     const float t1 = first_step_row(a, in, row1, top1);
     const uint32_t m1 = in.m;
     if (owner && k >= 2 && k <= n + 1) sum1 += t1;
-    if (k + 2 <= n + 3) {
+    const int kn = k + NBUF;
+    if (kn <= n + 3) {
       // source rows shared with the neighbouring chunk (its own sweep reads them too) stay cacheable
-      if (NTL == 2 && k + 2 >= 4 && k + 2 <= n - 1) issue_row_loads<true>(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
-      else issue_row_loads<NTL == 1>(a, wrap(r0 + (k + 2) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      if (NTL == 2 && kn >= 4 && kn <= n - 1) issue_row_loads<true>(a, wrap(r0 + kn * d), xcol, xhalo_w, xhalo_e, lane, in);
+      else issue_row_loads<NTL == 1>(a, wrap(r0 + kn * d), xcol, xhalo_w, xhalo_e, lane, in);
     }
     // level 2: state after step t+2 on the middle row of window 1 (row r0 + (k-1)*d), from the third iteration on
     uint32_t m2 = 0;
     if (k >= 2) {
       const int row2 = wrap(r0 + (k - 1) * d);
       float g[9][4];
-      window_gather(w1, top1, up, g);
-      m2 = w1.m_mid;
+      if (WLDS) lds_window_gather(lw1, par, top1, up, g);
+      else window_gather(w1, top1, up, g);
+      m2 = m_mid1;
       const float t2 = collide4(g, m2, a.omega, row2 == a.accel_row || row2 == a.accel_row_b, a.aw1, a.aw2, top2);
       if (owner && k >= 3 && k <= n + 2) sum2 += t2;
     }
+    if (WLDS) lds_window_put(lw1, par, top1, up);
+    else window_rotate(w1, top1, m1, up);
+    m_mid1 = m1;
     // level 3: step t+3 on the middle row of window 2 (row r0 + (k-2)*d), from the fifth iteration on
     if (k >= 4) {
       const int y = r0 + (k - 2) * d;
       float g[9][4], o[9][4];
-      window_gather(w2, top2, up, g);
-      const float t3 = collide4(g, w2.m_mid, a.omega, (y == a.accel_row || y == a.accel_row_b) && a.accel_next, a.aw1, a.aw2, o);
+      if (WLDS) lds_window_gather(lw2, par, top2, up, g);
+      else window_gather(w2, top2, up, g);
+      const float t3 = collide4(g, m_mid2, a.omega, (y == a.accel_row || y == a.accel_row_b) && a.accel_next, a.aw1, a.aw2, o);
       if (owner) {
         sum3 += t3;
         float *dp = a.dst + (size_t)y * a.row_stride + xcol;
@@ -697,12 +769,21 @@ __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *parti
         for (int kk = 0; kk < 9; kk++) store4<NT>(dp + kk * ps, o[kk][0], o[kk][1], o[kk][2], o[kk][3]);
       }
     }
-    if (k >= 2) window_rotate(w2, top2, m2, up);
-    window_rotate(w1, top1, m1, up);
+    if (k >= 2) {
+      if (WLDS) lds_window_put(lw2, par, top2, up);
+      else window_rotate(w2, top2, m2, up);
+      m_mid2 = m2;
+    }
   };
-  for (int k = 0; k <= n + 3; k += 2) {
-    iterate(k, inA);
-    if (k + 1 <= n + 3) iterate(k + 1, inB);
+  if (NBUF == 2) {
+    for (int k = 0; k <= n + 3; k += 2) {
+      iterate(k, inA, up);
+      if (k + 1 <= n + 3) iterate(k + 1, inB, up);
+    }
+  } else {
+    // (one copy of the loop per sweep direction, which folds the plane-role selects away, was 2 % slower:
+    // twice the code for the instruction cache)
+    for (int k = 0; k <= n + 3; k++) iterate(k, inA, up);
   }
   sum1 = wave_sum(sum1);
   sum2 = wave_sum(sum2);

@@ -99,6 +99,7 @@ int load_rccl() {
                   g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?");                      \
   } while (0)
 
+constexpr bool kStep3LdsDefault = true;   // d2q9_step3 windows in LDS unless option "windows" says otherwise
 constexpr int kRingMax = 256;  // most steps of per-workgroup partial sums buffered between reductions
 enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2 };
 
@@ -169,6 +170,9 @@ struct lbm_ctx {
   int nt_loads = -1;        // non-temporal source loads in d2q9_step2: -1 auto (with nt stores), 0 off, 1 on
   int fuse = -1;            // two timesteps per launch (d2q9_step2): -1 auto, 0 off, 1 on
   int tile_shape = -1;      // d2q9_multi tile: -1 auto, 0 = 32x16, 1 = 16x16, 2 = 16x8
+  int windows = -1;         // d2q9_step3 register windows: 0 = in registers (1 wave/SIMD), 1 = in LDS (2 waves/SIMD), -1 auto
+  int load_bufs = 0;        // d2q9_step3 row-sets of loads in flight: 1, 2, 0 = auto
+  int sched_waves = 0;      // waves per SIMD the d2q9_step3 schedule plans for: 1, 2, 0 = auto
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
   int chunk_min = 0;        // shortest chunk at the tapered end of a band (0 = auto)
@@ -212,6 +216,11 @@ void split_rows(int ny, int P, int idx, int *y0, int *rows) {
 }
 
 // two-steps-per-launch kernel: float4 rows of at least one wave, a few rows per slab
+bool windows_in_lds(const lbm_ctx *c) { return c->windows < 0 ? kStep3LdsDefault : c->windows != 0; }
+int step3_load_bufs(const lbm_ctx *c) { return c->load_bufs > 0 ? c->load_bufs : (windows_in_lds(c) ? 1 : 2); }
+
+int step3_sched_waves(const lbm_ctx *c) { return c->sched_waves > 0 ? c->sched_waves : (windows_in_lds(c) ? 2 : 1); }
+
 bool fuse_possible(const lbm_ctx *c) {
   if (!c->vec4 || c->p.nx < 256) return false;
   return c->rows_min >= 8;
@@ -224,11 +233,11 @@ int fuse_level(const lbm_ctx *c) {
   if (c->fuse >= 0) {
     lvl = c->fuse == 0 ? 0 : (c->fuse == 3 ? 3 : 2);
   } else {
-    // auto (same-box A/B, tools/ab_fuse3.py): below ~768x768 one launch per step / the LDS kernel win; two steps
-    // per launch up to 1536x1024 (127 vs 124 GLUPS); three steps per launch from 2048x1024 on (137 vs 124,
-    // 8192x8192: 188 vs 152)
+    // auto (same-box A/B, tools/ab_fuse3.py, GLUPS two-step / three-step): up to 1024x512 cells the LDS tile kernel
+    // wins (multistep_effective); above, three steps per launch everywhere: 768x768 89 / 89, 1024x768 106 / 111,
+    // 1024x1024 114 / 118, 1536x1024 127 / 147, 2048x2048 128 / 174, 4096x4096 151 / 213, 8192x8192 156 / 229
     const long cells = (long)c->p.nx * c->rows_min;
-    lvl = cells >= (2L << 20) ? 3 : (cells > 540L * 1024 ? 2 : 0);
+    lvl = cells > 540L * 1024 ? 3 : 0;
   }
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
   return lvl;
@@ -348,11 +357,14 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     int cmax = c->chunk_rows > 0 ? c->chunk_rows : (big ? 6 : 8);
     cmax = std::max(2, std::min(cmax, s.rows));
     const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), cmax));
-    // d2q9_step3: six redundant intermediate rows per chunk and one wave per SIMD -> long chunks (tools/ab_fuse3.py:
-    // 8192x8192 16/6: 178, 32/6: 186, 64/8: 188 GLUPS; 8192x1024: 32/6 159, 64/8 156)
-    int c3max = c->chunk_rows > 0 ? c->chunk_rows : (c->rows_min >= 2048 ? 64 : 32);
+    // d2q9_step3: six redundant intermediate rows per chunk.  With the windows in LDS (two waves per SIMD) the
+    // schedule is flat between 8/4 and 32/6 (tools/ab_fuse3.py, 8192x8192: 32/6 226, 16/6 229, 8/4 230, 6/2 224,
+    // 4/2 211 GLUPS; 4096x4096: 32/6 215, 16/6 213, 8/4 212; 8192x1024: 32/6 195, 16/6 201, 8/2 190); with register
+    // windows (one wave per SIMD) long chunks: 8192x8192 16/6 178, 32/6 186, 64/8 188
+    const bool w_lds = windows_in_lds(c);
+    int c3max = c->chunk_rows > 0 ? c->chunk_rows : (w_lds ? 16 : (c->rows_min >= 2048 ? 64 : 32));
     c3max = std::max(4, std::min(c3max, s.rows));
-    const int c3min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (c->rows_min >= 2048 ? 8 : 6), c3max));
+    const int c3min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (!w_lds && c->rows_min >= 2048 ? 8 : 6), c3max));
     if (multi) {
       // the two edge chunks hold the rows the neighbours need (2 each); the interior is everything else
       // (edge chunks are as short as the exchange allows — 2 rows when the halo depth is 2: an edge unit is one
@@ -372,7 +384,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       const int i0 = s.row0 + s.edge_rows, i1 = s.row0 + s.rows - s.edge_rows;
       if (i1 > i0) {
         if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main)) return rc;
-        if (int rc = fuse_schedule(s, i0, i1, c3max, c3min, true, s.f3_main, 1)) return rc;
+        if (int rc = fuse_schedule(s, i0, i1, c3max, c3min, true, s.f3_main, step3_sched_waves(c))) return rc;
       } else {
         s.f_main.units = s.f3_main.units = 0;
       }
@@ -380,7 +392,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     } else {
       if (int rc = fuse_schedule(s, 0, s.rows, cmax, cmin, true, s.f_main)) return rc;
       s.nb_total = std::max(s.nb_total, s.f_main.units);
-      if (int rc = fuse_schedule(s, 0, s.rows, c3max, c3min, true, s.f3_main, 1)) return rc;
+      if (int rc = fuse_schedule(s, 0, s.rows, c3max, c3min, true, s.f3_main, step3_sched_waves(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f3_main.units);
     }
   }
@@ -473,12 +485,22 @@ Step2Args base_args2(const lbm_ctx *c, const Slab &s, int src, bool accel_next, 
   return a;
 }
 
+template <bool WLDS, int NBUF>
+void launch_step3_v(int ntl, const Step2Args &a, float *partials3, int units, hipStream_t st) {
+  const dim3 grid(units), block(64);
+  if (ntl == 2) hipLaunchKernelGGL((d2q9_step3<true, 2, WLDS, NBUF>), grid, block, 0, st, a, partials3);
+  else if (ntl == 1) hipLaunchKernelGGL((d2q9_step3<true, 1, WLDS, NBUF>), grid, block, 0, st, a, partials3);
+  else hipLaunchKernelGGL((d2q9_step3<true, 0, WLDS, NBUF>), grid, block, 0, st, a, partials3);
+}
+
 void launch_step3(const lbm_ctx *c, const Step2Args &a, float *partials3, int units, hipStream_t st) {
   const int ntl = c->nt_loads >= 0 ? c->nt_loads : 2;
-  const dim3 grid(units), block(64);
-  if (ntl == 2) hipLaunchKernelGGL((d2q9_step3<true, 2>), grid, block, 0, st, a, partials3);
-  else if (ntl == 1) hipLaunchKernelGGL((d2q9_step3<true, 1>), grid, block, 0, st, a, partials3);
-  else hipLaunchKernelGGL((d2q9_step3<true, 0>), grid, block, 0, st, a, partials3);
+  const bool lds = windows_in_lds(c);
+  const bool one = step3_load_bufs(c) == 1;
+  if (lds && one) launch_step3_v<true, 1>(ntl, a, partials3, units, st);
+  else if (lds) launch_step3_v<true, 2>(ntl, a, partials3, units, st);
+  else if (one) launch_step3_v<false, 1>(ntl, a, partials3, units, st);
+  else launch_step3_v<false, 2>(ntl, a, partials3, units, st);
 }
 
 MultiArgs base_args_multi(const lbm_ctx *c, const Slab &s, int src, int T, bool accel_next) {
@@ -1242,6 +1264,12 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     c->tile_shape = (int)value;
     return rebuild_geometry(c);
   }
+  if (!strcmp(key, "windows") || !strcmp(key, "load_bufs") || !strcmp(key, "sched_waves")) {
+    if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "%s out of range", key);
+    if (int rc = sync_all(c)) return rc;
+    (key[0] == 'w' ? c->windows : (key[0] == 'l' ? c->load_bufs : c->sched_waves)) = (int)value;
+    return rebuild_geometry(c);
+  }
   if (!strcmp(key, "multistep")) {
     if (value < -1 || value > kMultiMaxT) return fail(LBM_ERR_ARG, "multistep must be -1..%d", kMultiMaxT);
     c->multistep = (int)value;
@@ -1272,7 +1300,9 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "fuse")) *value = fuse_level(c) == 3 ? 3 : (fuse_level(c) ? 1 : 0);
   else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
-  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : c->slabs[0].f_main.units + c->slabs[0].f_edge.units;
+  else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
+  else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
+  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;
   else return fail(LBM_ERR_ARG, "unknown option '%s'", key);

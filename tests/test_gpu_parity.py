@@ -144,9 +144,9 @@ def test_lds_multistep_equals_single_steps(lbm, oracle_f32_omp, nx, ny, T, nstep
 
 
 def test_default_kernel_choice_by_grid_size(lbm):
-    """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel for bandwidth-bound ones"""
-    expect = {(128, 128): (8, 0), (256, 256): (8, 0), (512, 512): (8, 0), (1024, 512): (8, 0), (768, 768): (0, 1),
-              (1024, 1024): (0, 1), (1536, 1024): (0, 1), (2048, 1024): (0, 3), (4096, 2048): (0, 3), (128, 8192): (0, 0)}
+    """auto policy: LDS multi-step kernel for launch-bound grids, three-step kernel for bandwidth-bound ones"""
+    expect = {(128, 128): (8, 0), (256, 256): (8, 0), (512, 512): (8, 0), (1024, 512): (8, 0), (768, 768): (0, 3),
+              (1024, 1024): (0, 3), (1536, 1024): (0, 3), (2048, 1024): (0, 3), (4096, 2048): (0, 3), (128, 8192): (0, 0)}
     for (nx, ny), (ms, fuse) in expect.items():
         ob = np.zeros((ny, nx), np.int32)
         with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
@@ -514,13 +514,16 @@ def test_odd_large_shapes_all_kernels_agree(lbm, nx, ny):
 @pytest.mark.parametrize("nx,ny,chunk", [(256, 8, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (2048, 16, 16), (260, 33, 4),
                                          (8192, 24, 8)])
 @pytest.mark.parametrize("nsteps", [3, 4, 5, 10])
-def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps):
-    """d2q9_step3 (three timesteps per launch, two register windows): bit-identical to single steps; step counts
-    that are no multiple of three finish with the two-step / single-step kernels"""
+@pytest.mark.parametrize("windows,bufs", [(1, 1), (0, 2), (1, 2), (0, 1)])
+def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, windows, bufs):
+    """d2q9_step3 (three timesteps per launch; the two windows of intermediate rows in LDS — the default — or in
+    registers, one or two row-sets of loads in flight): bit-identical to single steps; step counts that are no
+    multiple of three finish with the two-step / single-step kernels"""
     rng = np.random.default_rng(3 * nx + ny + nsteps)
     ob, cells0 = random_case(rng, nx, ny)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
-    got, av = run_gpu(lbm, p, ob, cells0, nsteps, {"multistep": 0, "fuse": 3, "chunk_rows": chunk})
+    got, av = run_gpu(lbm, p, ob, cells0, nsteps, {"multistep": 0, "fuse": 3, "windows": windows, "load_bufs": bufs,
+                                                   "chunk_rows": chunk})
     assert np.array_equal(got, single)
     assert max_rel(av, av_single) < 2e-6

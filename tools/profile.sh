@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 TAG=${1:-r01}
 EXTRA=${2:-}
-ARGS="--steps 60 --warmup 10 --no-cpu-baseline --no-extra $EXTRA"
+ARGS="--no-cpu-baseline --no-extra $EXTRA"  # default steps/warmup: the very command whose JSON line is reported
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -o stats -- python3 $REPO/bench.py $ARGS > $OUT/prof_${TAG}_stats.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_fetch -o fetch -- python3 $REPO/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extra $EXTRA > $OUT/prof_${TAG}_fetch.log 2>&1 || exit 1
