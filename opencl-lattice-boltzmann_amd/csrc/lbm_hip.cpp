@@ -233,11 +233,12 @@ int fuse_level(const lbm_ctx *c) {
   if (c->fuse >= 0) {
     lvl = c->fuse == 0 ? 0 : (c->fuse == 3 ? 3 : 2);
   } else {
-    // auto (same-box A/B, tools/ab_fuse3.py, GLUPS two-step / three-step): up to 1024x512 cells the LDS tile kernel
-    // wins (multistep_effective); above, three steps per launch everywhere: 768x768 89 / 89, 1024x768 106 / 111,
-    // 1024x1024 114 / 118, 1536x1024 127 / 147, 2048x2048 128 / 174, 4096x4096 151 / 213, 8192x8192 156 / 229
+    // auto (same-box A/B, tools/ab_mid.py + tools/ab_fuse3.py, GLUPS two-step / three-step): the smallest grids go
+    // to the LDS tile kernel (multistep_effective); 768x512 88 / 83, 1024x512 82 / 81, 768x768 89 / 89 -> two steps
+    // per launch; 1024x768 106 / 111, 1024x1024 114 / 118, 1536x1024 127 / 147, 2048x2048 128 / 174,
+    // 4096x4096 151 / 213, 8192x8192 156 / 229 -> three steps per launch
     const long cells = (long)c->p.nx * c->rows_min;
-    lvl = cells > 540L * 1024 ? 3 : 0;
+    lvl = cells > 700L * 1024 ? 3 : 2;
   }
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
   return lvl;
@@ -252,9 +253,11 @@ int multistep_effective(const lbm_ctx *c) {
   const int cap = c->halo_mode ? std::min(kMultiMaxT, c->halo_depth) : kMultiMaxT;
   if (c->halo_mode && c->halo_depth < kMultiMaxT && c->multistep < 0) return 0;  // big slabs: two-step kernel
   if (c->multistep >= 0) return std::min(c->multistep, cap);
-  // auto: up to 1024x512 cells (profiles/r01_kernel_choice.txt: 128x128 1.7 us/step against 3.8 with one launch
-  // per step, 1024x512 6.7 against 7.4 for the two-step kernel; from 768x768 on the two-step kernel wins)
-  return ((long)c->p.nx * c->rows_min <= 540L * 1024) ? cap : 0;
+  // auto (profiles/r01_kernel_choice.txt, us/step LDS tiles / two-step kernel): 128x128 1.4 / 5, 384x384 3.4 / 4.2,
+  // 512x512 3.9 / 4.4, 768x512 5.6 / 4.5, 1024x512 7.3 / 6.4 -> up to 300K cells on one slab.  Slabs that exchange
+  // halos keep it up to 1024x512 cells: 8 steps per exchange instead of 2 (1024x512 ring of one: 9 against 25 us/step)
+  const long limit = c->halo_mode ? 540L * 1024 : 300L * 1024;
+  return ((long)c->p.nx * c->rows_min <= limit) ? cap : 0;
 }
 
 // Work decomposition of d2q9_step2 over stored rows [r0, r1): strips x chunks.  A unit's cost is

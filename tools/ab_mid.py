@@ -3,13 +3,13 @@ import sys
 import numpy as np
 sys.path.insert(0, '.')
 import lbm_amd
-for (nx, ny) in [(384, 384), (512, 512), (768, 512), (1024, 512), (768, 768), (1024, 768), (1024, 1024), (1536, 1024), (2048, 2048)]:
+for (nx, ny) in [(384, 384), (512, 512), (768, 512), (1024, 512), (768, 768), (1024, 768), (1024, 1024), (1536, 1024), (2048, 2048), (4096, 4096)]:
     ob = np.zeros((ny, nx), np.int32); ob[0, :] = ob[-1, :] = 1; ob[:, 0] = ob[:, -1] = 1
     p = lbm_amd.make_params(nx, ny, 400000, obstacles=ob)
-    steps = max(200, int(4e8 / (nx * ny)) // 8 * 8)
+    steps = max(240, int(4e8 / (nx * ny)) // 24 * 24)
     with lbm_amd.LBM(p, ob) as sim:
         row = []
-        for (ms, fuse) in [(0, 0), (0, 1), (4, 0), (8, 0)]:
+        for (ms, fuse) in [(0, 0), (0, 1), (0, 3), (4, 0), (8, 0)]:
             sim.set_option("fuse", fuse); sim.set_option("multistep", ms)
             sim.upload(None); sim.run(96)
             best = min(sim.run_timed(steps) for _ in range(3))
