@@ -164,7 +164,10 @@ def main():
     # one GPU per rank; if the launcher narrowed the visible devices per rank, index within what is visible
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    dist = init_dist("nccl", rank, world, torch.device("cuda", local_rank)) if world > 1 else None
+    # LBM_BENCH_RANK_MODE=1 (with LBM_FORCE_HALO=1) drives the one-process-per-GPU code path with a single rank: the
+    # rank is its own ring neighbour, so torch.distributed + the library's RCCL communicator run on a one-GPU box
+    rank_mode = world > 1 or os.environ.get("LBM_BENCH_RANK_MODE") == "1"
+    dist = init_dist("nccl", rank, world, torch.device("cuda", local_rank)) if rank_mode else None
 
     nx = args.nx
     ny = args.ny * (world if args.scaling == "weak" else 1)
@@ -172,7 +175,7 @@ def main():
     obstacles = make_workload(args.workload, nx, ny)
     params = lbm_amd.make_params(nx, ny, total_steps, 10, 0.1, args.accel, 1.85, obstacles)
 
-    if world > 1:
+    if rank_mode:
         cid = share_comm_id(dist, rank, lbm_amd.comm_id() if rank == 0 else None,
                             lbm_amd.load_library().lbm_comm_id_size(), torch.device("cuda", local_rank))
         sim = lbm_amd.LBM(params, obstacles, rank=rank, nranks=world, device=local_rank, comm=cid)

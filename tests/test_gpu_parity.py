@@ -460,6 +460,29 @@ def test_bench_json_contract():
     assert j["result_ok"] is True
 
 
+def test_bench_one_process_per_gpu_path_single_rank():
+    """the driver's multi-GPU launch line (torch.distributed.run, one rank per GPU, RCCL) with ONE rank that is its
+    own ring neighbour: torch.distributed's nccl backend and the library's RCCL communicator (ncclCommInitRank from
+    the broadcast id, grouped send/recv halos, all-reduce of the velocity sums) in one process on the real GPU"""
+    import json
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LBM_BENCH_RANK_MODE="1", LBM_FORCE_HALO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "60", "--warmup", "12", "--nx", "2048", "--ny", "1024", "--no-extra",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["result_ok"] is True and j["value"] > 1000
+    assert j["roofline"]["steps_per_launch"] == 3
+
+
 def test_abi_error_behaviour(lbm):
     """non-zero return codes + lbm_last_error() messages instead of the reference's print-and-exit (d2q9-bgk.c:858-866)"""
     import ctypes
