@@ -107,6 +107,7 @@ enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2 };
 struct FuseGeom {
   int *chunk_start = nullptr;  // device array [nchunks+1]
   int nchunks = 0, nbands = 1, units_per_band = 0, units = 0;
+  int skip = -1;               // chunk whose units do nothing (the interior, in an edge schedule)
 };
 
 struct Slab {
@@ -373,16 +374,27 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       // (edge chunks are as short as the exchange allows — 2 rows when the halo depth is 2: an edge unit is one
       // wave's serial sweep and, with the exchange, the critical path of a launch set, profiles/r01_overlap_trace.txt)
       FuseGeom &e = s.f_edge;
-      // edge schedule: chunk table {bottom edge, interior, top edge}; the launch skips chunk 1
-      std::vector<int> tab = {s.row0, s.row0 + s.edge_rows, s.row0 + s.rows - s.edge_rows, s.row0 + s.rows};
+      // edge schedule: chunk table {bottom edge rows, interior, top edge rows}; the launch skips the interior chunk.
+      // One chunk per edge by default.  Splitting an edge into single-row chunks (LBM_EDGE_CHUNK=1) shortens the edge
+      // kernel of d2q9_step3 from 47 to 32 us (5 instead of 7 iterations per wave) but did not shorten the launch set:
+      // 8192x1024 ring of one 45.5 -> 47.0 us/step, 4096x512 18.3 -> 17.0, 2048x256 9.1 -> 9.3 (tools/ab_edge.sh)
+      int ec = s.edge_rows;
+      if (const char *v = getenv("LBM_EDGE_CHUNK")) ec = std::max(1, atoi(v));  // tuning: rows per edge chunk
+      std::vector<int> tab;
+      for (int y = 0; y < s.edge_rows; y += ec) tab.push_back(s.row0 + y);
+      const int n_edge_chunks = (int)tab.size();
+      tab.push_back(s.row0 + s.edge_rows);
+      for (int y = 0; y < s.edge_rows; y += ec) tab.push_back(s.row0 + s.rows - s.edge_rows + y);
+      tab.push_back(s.row0 + s.rows);
       if (set_dev(s)) return LBM_ERR_HIP;
       if (e.chunk_start) HIP_TRY(hipFree(e.chunk_start));
       e.chunk_start = nullptr;
       if (dev_alloc(&e.chunk_start, tab.size())) return LBM_ERR_HIP;
       HIP_TRY(hipMemcpy(e.chunk_start, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-      e.nchunks = 3;  // chunk 1 = [row0+edge, row0+rows-edge) is skipped by the kernel (edge_only)
+      e.nchunks = 2 * n_edge_chunks + 1;  // the middle chunk [row0+edge, row0+rows-edge) is skipped by the kernel
+      e.skip = n_edge_chunks;
       e.nbands = 1;
-      e.units_per_band = 3 * s.strips;
+      e.units_per_band = e.nchunks * s.strips;
       e.units = e.units_per_band;
       const int i0 = s.row0 + s.edge_rows, i1 = s.row0 + s.rows - s.edge_rows;
       if (i1 > i0) {
@@ -735,7 +747,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       } else if (kind == KIND_FUSED3) {
         float *slot3 = slot2 + s.nb_total;
         Step2Args e = base_args2(c, s, src, !last, s.f_edge);
-        e.skip_chunk = 1;  // chunk table {bottom edge, (interior), top edge}
+        e.skip_chunk = s.f_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
         e.partials1 = slot1 + s.f3_main.units;
         e.partials2 = slot2 + s.f3_main.units;
         launch_step3(c, e, slot3 + s.f3_main.units, s.f_edge.units, s.s_edge);
@@ -749,7 +761,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
         }
       } else if (kind == KIND_FUSED2) {
         Step2Args e = base_args2(c, s, src, !last, s.f_edge);
-        e.skip_chunk = 1;  // chunk table {bottom edge, (interior), top edge}
+        e.skip_chunk = s.f_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
         e.partials1 = slot1 + s.f_main.units;
         e.partials2 = slot2 + s.f_main.units;
         launch_step2(c, e, s.f_edge.units, s.s_edge);
