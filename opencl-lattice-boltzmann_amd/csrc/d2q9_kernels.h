@@ -980,6 +980,19 @@ __global__ void init_cells(float *cells, unsigned long long plane_stride, unsign
   }
 }
 
+// ---- read-back: row-interleaved device layout -> the reference's plane-major float[9][rows][nx] -------
+// (into the grid that is not current — scratch between runs — so that the device-to-host transfer is nine large
+// contiguous copies instead of 9*rows strided ones)
+__global__ void pack_planes(const float *cells, unsigned long long plane_stride, unsigned long long row_stride, int nx,
+                            size_t n, float *out) {
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
+    const size_t y = c / nx;
+    const size_t i = y * row_stride + (c - y * nx);
+#pragma unroll
+    for (int k = 0; k < 9; k++) out[k * n + c] = cells[k * plane_stride + i];
+  }
+}
+
 // ---- output stage: columns of final_state.dat + velocity sum (d2q9-bgk.c:787-832, 396-442) ------
 __global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsigned long long plane_stride,
                                                        unsigned long long row_stride, int nx, const uint8_t *mask,
