@@ -435,6 +435,35 @@ def test_8192x8192_vs_oracle_and_mass(lbm, oracle_f32_omp):
     assert np.all(np.diff(av[:40]) > 0)  # the lid keeps accelerating the cavity from rest
 
 
+def test_y_extension_invariance_16384x16384(lbm):
+    """a grid whose arrays exceed 2^31 floats (16384x16384: 2.4e9 floats per grid): for fewer steps than rows the flow
+    only knows the rows around the accelerated row ny-2, so the 96 rows around it — and the velocity sums — must equal
+    those of a 16384x1024 grid bit for bit (same obstacles there); everything below stays at rest.  Catches 32-bit
+    index arithmetic on rows near the end of the big arrays"""
+    nx, big, small, nsteps, win = 16384, 16384, 1024, 30, 64
+    rng = np.random.default_rng(99)
+    band = (rng.random((2 * win, nx)) < 0.02).astype(np.int32)   # obstacles only in the compared window
+    res = {}
+    for ny in (small, big):
+        ob = np.zeros((ny, nx), np.int32)
+        ob[ny - win:, :] = band[:win]
+        ob[:win, :] = band[win:]
+        p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+        p.free_cells_inv = np.float32(1.0)   # raw sums of |j|/rho, comparable between the two grids
+        with lbm.LBM(p, ob) as sim:
+            del ob
+            sim.upload(None)
+            sim.run(nsteps)
+            cells, av = sim.download()
+        res[ny] = (np.concatenate([cells[:, ny - win:, :], cells[:, :win, :]], axis=1).copy(), av,
+                   cells[:, win:ny - win, :].max(axis=(1, 2)), cells[:, win:ny - win, :].min(axis=(1, 2)))
+        del cells
+    assert np.array_equal(res[small][0], res[big][0])
+    assert max_rel(res[big][1], res[small][1]) < 2e-6
+    for ny in (small, big):   # outside the window nothing has moved: every plane is still uniform
+        assert np.array_equal(res[ny][2], res[ny][3])
+
+
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` (small grid here)"""
     import json
