@@ -265,7 +265,8 @@ int multistep_effective(const lbm_ctx *c) {
 // proportional to its rows + 2 and all units of a launch finish at about the same time, so equal chunks
 // leave the chip partly idle during the last round of units (17 % of the launch with 32-row chunks on
 // 8192x8192).  The schedule therefore tapers: every band (the share of one XCD) starts with chunks of
-// `cmax` rows and ends with ever shorter ones (guided self-scheduling), down to `cmin`.
+// `cmax` rows and ends with ever shorter ones (guided self-scheduling), down to `cmin`.  (R full rounds of equal
+// chunks instead of the taper: within +-2 % on 8192x1024 ... 8192x8192, no consistent sign — not adopted.)
 int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g, int waves_per_simd = 2) {
   const int rows = r1 - r0;
   g.nbands = (allow_bands && rows >= 8 * 4 * cmin) ? 8 : 1;
