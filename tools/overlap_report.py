@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/overlap_report.py <kernel_trace.csv> — how much of the halo exchange (RCCL kernels) and of the edge
-launch runs concurrently with the interior launch of the two-step kernel."""
+launch runs concurrently with the interior launch of the multi-step kernels (d2q9_step2/3: edge = the small grid; d2q9_multi: edge = the launch with fewer tile rows)."""
 import csv
 import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -8,7 +8,7 @@ iv = {"interior": [], "edge": [], "rccl": []}
 for r in rows:
     name, st, en = r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
-    if "d2q9_step2" in name or "d2q9_step3" in name:
+    if "d2q9_step2" in name or "d2q9_step3" in name or "d2q9_multi" in name:
         iv["pending"] = iv.get("pending", []) + [(st, en, grid)]
     elif "nccl" in name.lower() or "rccl" in name.lower():
         iv["rccl"].append((st, en))
