@@ -139,8 +139,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "chunk_min"    fewest rows per wave at the tapered end of the schedule (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)
  *   "nt_stores"    1 = non-temporal stores for the destination grid, 0 = plain, -1 = auto
- *   "nt_loads"     source loads of the two-step kernel: 0 = plain, 1 = non-temporal, 2 = non-temporal except
- *                  for the rows shared with the neighbouring chunk, -1 = auto (2)
+ *   "nt_loads"     source loads of the multi-step kernels: 0 = plain, 1 = non-temporal, 2 = non-temporal except
+ *                  for the rows shared with the neighbouring chunk, -1 = auto (2 for the two-step kernel, 0 for
+ *                  the three-step kernel with its windows in LDS)
  * Read-only through lbm_get_option: "transport" (1 = RCCL send/recv, 2 = device-to-device copies; chosen at
  * creation, environment LBM_TRANSPORT=rccl|copy overrides for single-process contexts), "nslabs", "fuse_units".
  */

@@ -510,8 +510,12 @@ void launch_step3_v(int ntl, const Step2Args &a, float *partials3, int units, hi
 }
 
 void launch_step3(const lbm_ctx *c, const Step2Args &a, float *partials3, int units, hipStream_t st) {
-  const int ntl = c->nt_loads >= 0 ? c->nt_loads : 2;
   const bool lds = windows_in_lds(c);
+  // source loads: with two waves per SIMD (LDS windows) plain loads win at every size — 8192x8192 227.6 against 221.4
+  // GLUPS with the hybrid scheme, 202.3 all non-temporal; 2048x2048 180.8 / 175.2 / 165.3; 1024x1024 117.9 / 116.4 /
+  // 106.0 (tools/ab_mid4.py) — the rows a chunk shares with its neighbours and the strips' edge lines stay in L2;
+  // with one wave per SIMD (register windows) the lower latency of the hybrid scheme was worth more
+  const int ntl = c->nt_loads >= 0 ? c->nt_loads : (lds ? 0 : 2);
   const bool one = step3_load_bufs(c) == 1;
   if (lds && one) launch_step3_v<true, 1>(ntl, a, partials3, units, st);
   else if (lds) launch_step3_v<true, 2>(ntl, a, partials3, units, st);
