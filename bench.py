@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the nx x ny grid is split over the ranks; weak: every rank gets ny rows")
     ap.add_argument("--accel", type=float, default=0.005)
-    ap.add_argument("--fuse", type=int, default=-1, help="1/0: two timesteps per launch on/off, -1: library default")
+    ap.add_argument("--fuse", type=int, default=-1, help="timesteps per launch of the register/LDS-window kernels: 0, 1 (= 2), 3, 4; -1: library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 1024x1024 side measurement")
     args = ap.parse_args()
@@ -183,7 +183,7 @@ def main():
         sim = lbm_amd.LBM(params, obstacles)
     if args.fuse >= 0:
         sim.set_option("fuse", args.fuse)
-    fused = {0: 0, 1: 2, 3: 3}[sim.get_option("fuse")]   # timesteps per launch of the dominant kernel (0: one)
+    fused = {0: 0, 1: 2, 3: 3, 4: 4}[sim.get_option("fuse")]   # timesteps per launch of the dominant kernel (0: one)
     sim.upload(None)  # uniform rest state, built on the device
     y0, y1 = sim.row_range()
 
@@ -229,7 +229,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "kernel": {0: "d2q9_step", 2: "d2q9_step2 (two timesteps per launch)",
-                                    3: "d2q9_step3 (three timesteps per launch)"}[fused],
+                                    3: "d2q9_step3 (three timesteps per launch)",
+                                    4: "d2q9_step4 (four timesteps per launch)"}[fused],
                          "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "result_ok": ok,

@@ -795,6 +795,116 @@ __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *parti
   }
 }
 
+// ---- four timesteps per launch ------------------------------------------------------------------------
+// d2q9_step3 with one more level: windows 1 and 2 in LDS as before (18 KB per wave is all the LDS two waves per SIMD
+// leave), window 3 in the registers that kernel leaves free.  Level-1 rows k = 0 .. n+5 (row r0 + k*d), level-2 row
+// k-1 from k = 2, level-3 row k-2 from k = 4, output row k-3 from k = 6.  One cell of the outermost lane becomes
+// invalid per level, so the two halo lanes per side of d2q9_step3 are enough here too (60 output lanes).
+template <bool NT, int NTL = 0>
+__global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *partials3, float *partials4) {
+  __shared__ v4f win[2 * kWinSlots * 64];
+  const int lane = threadIdx.x;
+  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
+  if (slot >= a.units_per_band) return;
+  const int unit = band * a.units_per_band + slot;
+  const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
+  const int ys = a.chunk_start[chunk];
+  const int ye = a.chunk_start[chunk + 1];
+  if (ys >= ye || chunk == a.skip_chunk) {
+    if (lane == 0) a.partials1[unit] = a.partials2[unit] = partials3[unit] = partials4[unit] = 0.f;
+    return;
+  }
+  const int q4 = a.nx >> 2;
+  const int qcol = strip * a.lanes_out + lane - 2;
+  const bool owner = (lane >= 2) && (lane < 2 + a.lanes_out) && (qcol < q4);
+  int qw = qcol % q4;
+  if (qw < 0) qw += q4;
+  const int xcol = qw * 4;
+  const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
+  const int xhalo_e = (xcol + 4 >= a.nx) ? 0 : xcol + 4;
+  const size_t ps = a.plane_stride;
+  auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
+  const bool up = __builtin_amdgcn_readfirstlane((int)((chunk & 1) == 0)) != 0;
+  const int n = ye - ys;
+  const int d = up ? 1 : -1;
+  const int r0 = up ? ys - 3 : ye + 2;
+
+  float sum1 = 0.f, sum2 = 0.f, sum3 = 0.f, sum4 = 0.f;
+  v4f *const lw1 = win + lane, *const lw2 = win + kWinSlots * 64 + lane;
+  Window w3;
+  uint32_t m_mid1 = 0, m_mid2 = 0, m_mid3 = 0;
+  float top1[9][4], top2[9][4], top3[9][4];
+  RowLoads in;
+  issue_row_loads<NTL == 1>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, in);
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) w3.trail[k][v] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) w3.mid[k][v] = 0.f;
+  }
+  for (int k = 0; k <= n + 5; k++) {
+    const int par = k & 1;
+    const int row1 = wrap(r0 + k * d);
+    const float t1 = first_step_row(a, in, row1, top1);
+    const uint32_t m1 = in.m;
+    if (owner && k >= 3 && k <= n + 2) sum1 += t1;
+    if (k + 1 <= n + 5) {
+      if (NTL == 2 && k + 1 >= 6 && k + 1 <= n - 1) issue_row_loads<true>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      else issue_row_loads<NTL == 1>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    }
+    uint32_t m2 = 0, m3 = 0;
+    if (k >= 2) {
+      const int row2 = wrap(r0 + (k - 1) * d);
+      float g[9][4];
+      lds_window_gather(lw1, par, top1, up, g);
+      m2 = m_mid1;
+      const float t2 = collide4(g, m2, a.omega, row2 == a.accel_row || row2 == a.accel_row_b, a.aw1, a.aw2, top2);
+      if (owner && k >= 4 && k <= n + 3) sum2 += t2;
+    }
+    lds_window_put(lw1, par, top1, up);
+    m_mid1 = m1;
+    if (k >= 4) {
+      const int row3 = wrap(r0 + (k - 2) * d);
+      float g[9][4];
+      lds_window_gather(lw2, par, top2, up, g);
+      m3 = m_mid2;
+      const float t3 = collide4(g, m3, a.omega, row3 == a.accel_row || row3 == a.accel_row_b, a.aw1, a.aw2, top3);
+      if (owner && k >= 5 && k <= n + 4) sum3 += t3;
+    }
+    if (k >= 2) {
+      lds_window_put(lw2, par, top2, up);
+      m_mid2 = m2;
+    }
+    if (k >= 6) {
+      const int y = r0 + (k - 3) * d;
+      float g[9][4], o[9][4];
+      window_gather(w3, top3, up, g);
+      const float t4 = collide4(g, m_mid3, a.omega, (y == a.accel_row || y == a.accel_row_b) && a.accel_next, a.aw1, a.aw2, o);
+      if (owner) {
+        sum4 += t4;
+        float *dp = a.dst + (size_t)y * a.row_stride + xcol;
+#pragma unroll
+        for (int kk = 0; kk < 9; kk++) store4<NT>(dp + kk * ps, o[kk][0], o[kk][1], o[kk][2], o[kk][3]);
+      }
+    }
+    if (k >= 4) {
+      window_rotate(w3, top3, m3, up);
+      m_mid3 = m3;
+    }
+  }
+  sum1 = wave_sum(sum1);
+  sum2 = wave_sum(sum2);
+  sum3 = wave_sum(sum3);
+  sum4 = wave_sum(sum4);
+  if (lane == 0) {
+    a.partials1[unit] = sum1;
+    a.partials2[unit] = sum2;
+    partials3[unit] = sum3;
+    partials4[unit] = sum4;
+  }
+}
+
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------
 // Grids of a few hundred cells a side are bound by launch latency, not bandwidth (one step of 128x128 is
 // ~2 us of work behind ~3.4 us of launch cost).  This kernel advances T <= kMultiMaxT steps per launch: a

@@ -128,7 +128,8 @@ struct Slab {
   int nb_total = 0;              // slot stride of the ring
   int strips = 0, lanes_out = 0;  // x decomposition of d2q9_step2
   FuseGeom f_main, f_edge;        // whole slab (one slab) or interior chunks; the two edge chunks
-  FuseGeom f3_main;               // schedule of d2q9_step3 (one slab): 1 wave per SIMD, longer chunks
+  FuseGeom f3_main;               // schedule of d2q9_step3: its own chunk lengths
+  FuseGeom f4_main;               // schedule of d2q9_step4 (one slab only): long chunks
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
   int m_tx = 32, m_ty = 16;          // its tile size (chosen by how many tiles the slab gives)
@@ -232,15 +233,18 @@ int fuse_level(const lbm_ctx *c) {
   if (!fuse_possible(c)) return 0;
   int lvl;
   if (c->fuse >= 0) {
-    lvl = c->fuse == 0 ? 0 : (c->fuse == 3 ? 3 : 2);
+    lvl = c->fuse == 0 ? 0 : (c->fuse >= 3 ? c->fuse : 2);
   } else {
     // auto (same-box A/B, tools/ab_mid.py + tools/ab_fuse3.py, GLUPS two-step / three-step): the smallest grids go
     // to the LDS tile kernel (multistep_effective); 768x512 88 / 83, 1024x512 82 / 81, 768x768 89 / 89 -> two steps
     // per launch; 1024x768 106 / 111, 1024x1024 114 / 118, 1536x1024 127 / 147, 2048x2048 128 / 174,
     // 4096x4096 151 / 213, 8192x8192 156 / 229 -> three steps per launch
+    // ... and four steps per launch from 8M cells up on one slab (tools/ab_step4d.py, three / four steps: 3072x2048 196 /
+    // 195, 4096x2048 205 / 208, 4096x3072 214 / 222, 4096x4096 217 / 232, 8192x8192 232 / 251, 16384x16384 240 / 275)
     const long cells = (long)c->p.nx * c->rows_min;
-    lvl = cells > 700L * 1024 ? 3 : 2;
+    lvl = cells >= (8L << 20) ? 4 : (cells > 700L * 1024 ? 3 : 2);
   }
+  if (lvl == 4 && (c->halo_mode || !windows_in_lds(c))) lvl = 3;  // four steps per launch: one slab, LDS windows
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
   return lvl;
 }
@@ -410,6 +414,12 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       s.nb_total = std::max(s.nb_total, s.f_main.units);
       if (int rc = fuse_schedule(s, 0, s.rows, c3max, c3min, true, s.f3_main, step3_sched_waves(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f3_main.units);
+      // d2q9_step4: twelve redundant intermediate rows per chunk -> long chunks (tools/ab_step4b.py, 8192x8192:
+      // 32/8 247, 64/16 253, 128/32 255 GLUPS; 16384x16384: 32/8 260, 64/16 269, 128/32 273)
+      const int c4max = std::max(4, std::min(c->chunk_rows > 0 ? c->chunk_rows : 128, s.rows));
+      const int c4min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : 32, c4max));
+      if (int rc = fuse_schedule(s, 0, s.rows, c4max, c4min, true, s.f4_main, 2)) return rc;
+      s.nb_total = std::max(s.nb_total, s.f4_main.units);
     }
   }
   return LBM_OK;
@@ -648,7 +658,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     }
 
   int batch_first = c->steps_done;
-  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4 };
+  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4, KIND_FUSED4 = 5 };
   int batch_kind = KIND_NONE;  // launch kind of the steps buffered in the ring (their slot occupancy differs)
   int last_q = 1;
   const int multi_T = multistep_effective(c);
@@ -662,6 +672,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       int used = s.nb_main + s.nb_edge;
       if (batch_kind == KIND_FUSED2) used = s.f_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED3) used = s.f3_main.units + (multi ? s.f_edge.units : 0);
+      if (batch_kind == KIND_FUSED4) used = s.f4_main.units;
       if (batch_kind == KIND_MULTI) used = s.m_tiles_x * s.m_tiles_y;
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
@@ -685,7 +696,10 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     if (multi_T > 0) {
       kind = KIND_MULTI;
       adv = std::min(multi_T, nsteps - i);
-    } else if (fuse_lvl == 3 && nsteps - i >= 3) {
+    } else if (fuse_lvl == 4 && nsteps - i >= 4) {
+      kind = KIND_FUSED4;
+      adv = 4;
+    } else if (fuse_lvl >= 3 && nsteps - i >= 3) {
       kind = KIND_FUSED3;
       adv = 3;
     } else if (fuse && nsteps - i >= 2) {
@@ -707,6 +721,16 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           a.partials = slot1;
           a.ty_begin = 0; a.ty_split = s.m_tiles_y; a.ty_begin2 = 0;
           launch_multi(s, a, s.m_tiles_y, s.s_main);
+        } else if (kind == KIND_FUSED4) {
+          Step2Args a = base_args2(c, s, src, !last, s.f4_main);
+          a.partials1 = slot1;
+          a.partials2 = slot2;
+          float *slot3 = slot2 + s.nb_total;
+          const int ntl = c->nt_loads >= 0 ? c->nt_loads : 0;
+          const dim3 grid(s.f4_main.units), block(64);
+          if (ntl == 2) hipLaunchKernelGGL((d2q9_step4<true, 2>), grid, block, 0, s.s_main, a, slot3, slot3 + s.nb_total);
+          else if (ntl == 1) hipLaunchKernelGGL((d2q9_step4<true, 1>), grid, block, 0, s.s_main, a, slot3, slot3 + s.nb_total);
+          else hipLaunchKernelGGL((d2q9_step4<true, 0>), grid, block, 0, s.s_main, a, slot3, slot3 + s.nb_total);
         } else if (kind == KIND_FUSED3) {
           Step2Args a = base_args2(c, s, src, !last, s.f3_main);
           a.partials1 = slot1;
@@ -849,6 +873,7 @@ void free_slab(Slab &s) {
   if (s.f_main.chunk_start) hipFree(s.f_main.chunk_start);
   if (s.f_edge.chunk_start) hipFree(s.f_edge.chunk_start);
   if (s.f3_main.chunk_start) hipFree(s.f3_main.chunk_start);
+  if (s.f4_main.chunk_start) hipFree(s.f4_main.chunk_start);
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
@@ -1324,12 +1349,12 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   if (!strcmp(key, "variant")) *value = effective_mode(c) + 1;
   else if (!strcmp(key, "grid_blocks")) *value = c->slabs.empty() ? 0 : c->slabs[0].nb_main;
   else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
-  else if (!strcmp(key, "fuse")) *value = fuse_level(c) == 3 ? 3 : (fuse_level(c) ? 1 : 0);
+  else if (!strcmp(key, "fuse")) *value = fuse_level(c) >= 3 ? fuse_level(c) : (fuse_level(c) ? 1 : 0);
   else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
-  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units) + c->slabs[0].f_edge.units;
+  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units) + c->slabs[0].f_edge.units);
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;
   else return fail(LBM_ERR_ARG, "unknown option '%s'", key);

@@ -23,6 +23,7 @@ RTOL_AV = 1e-4
 SINGLE = {"fuse": 0, "multistep": 0}
 FUSED2 = {"fuse": 1, "multistep": 0}
 FUSED3 = {"fuse": 3, "multistep": 0}
+FUSED4 = {"fuse": 4, "multistep": 0}
 
 
 def max_rel(a, b):
@@ -147,7 +148,7 @@ def test_default_kernel_choice_by_grid_size(lbm):
     """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel in between, three-step kernel for
     bandwidth-bound ones"""
     expect = {(128, 128): (8, 0), (256, 256): (8, 0), (512, 512): (8, 0), (1024, 512): (0, 1), (768, 768): (0, 1),
-              (1024, 1024): (0, 3), (1536, 1024): (0, 3), (2048, 1024): (0, 3), (4096, 2048): (0, 3), (128, 8192): (0, 0)}
+              (1024, 1024): (0, 3), (1536, 1024): (0, 3), (2048, 1024): (0, 3), (3072, 2048): (0, 3), (4096, 2048): (0, 4), (128, 8192): (0, 0)}
     for (nx, ny), (ms, fuse) in expect.items():
         ob = np.zeros((ny, nx), np.int32)
         with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
@@ -509,7 +510,7 @@ def test_bench_one_process_per_gpu_path_single_rank():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["result_ok"] is True and j["value"] > 1000
-    assert j["roofline"]["steps_per_launch"] == 3
+    assert j["roofline"]["steps_per_launch"] == 3   # row slabs: the three-step kernel, whatever the size
 
 
 def test_abi_error_behaviour(lbm):
@@ -557,8 +558,8 @@ def test_odd_large_shapes_all_kernels_agree(lbm, nx, ny):
     nsteps = 7
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     base, av_base = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
-    for opts, kw in ((FUSED2, {}), (FUSED3, {}), ({"multistep": 4}, {}), (FUSED2, {"devices": [0, 0, 0, 0]}),
-                     (FUSED3, {"devices": [0, 0, 0]}), ({}, {"devices": [0, 0]})):
+    for opts, kw in ((FUSED2, {}), (FUSED3, {}), (FUSED4, {}), ({"multistep": 4}, {}), (FUSED2, {"devices": [0, 0, 0, 0]}),
+                     (FUSED3, {"devices": [0, 0, 0]}), (FUSED4, {"devices": [0, 0]}), ({}, {"devices": [0, 0]})):
         got, av = run_gpu(lbm, p, ob, cells0, nsteps, opts, **kw)
         assert np.array_equal(got, base), (opts, kw)
         assert max_rel(av, av_base) < 2e-6
@@ -578,5 +579,26 @@ def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, 
     single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     got, av = run_gpu(lbm, p, ob, cells0, nsteps, {"multistep": 0, "fuse": 3, "windows": windows, "load_bufs": bufs,
                                                    "chunk_rows": chunk})
+    assert np.array_equal(got, single)
+    assert max_rel(av, av_single) < 2e-6
+
+
+@pytest.mark.parametrize("nx,ny,chunk", [(256, 8, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (2048, 16, 16), (260, 33, 4),
+                                         (8192, 24, 8), (1024, 300, 128)])
+@pytest.mark.parametrize("nsteps", [4, 5, 6, 7, 13])
+def test_four_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps):
+    """d2q9_step4 (four timesteps per launch: two LDS windows + one register window): bit-identical to single steps;
+    the steps left over after the last full launch go to the three-step / two-step / single-step kernels"""
+    rng = np.random.default_rng(4 * nx + ny + nsteps)
+    ob, cells0 = random_case(rng, nx, ny)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob) as sim:
+        for k, v in {"multistep": 0, "fuse": 4, "chunk_rows": chunk}.items():
+            sim.set_option(k, v)
+        assert sim.get_option("fuse") == 4
+        sim.upload(cells0)
+        sim.run(nsteps)
+        got, av = sim.download()
     assert np.array_equal(got, single)
     assert max_rel(av, av_single) < 2e-6

@@ -1,0 +1,17 @@
+"""ad-hoc: long chunks for d2q9_step4 / d2q9_step3"""
+import sys
+import numpy as np
+sys.path.insert(0, '.')
+import lbm_amd
+for (nx, ny, steps) in [(4096, 4096, 480), (8192, 2048, 480), (5120, 5120, 240), (8192, 8192, 240), (16384, 16384, 96)]:
+    ob = np.zeros((ny, nx), np.int32); ob[0, :] = ob[-1, :] = 1; ob[:, 0] = ob[:, -1] = 1
+    p = lbm_amd.make_params(nx, ny, 100000, obstacles=ob)
+    with lbm_amd.LBM(p, ob) as sim:
+        del ob
+        sim.set_option("multistep", 0)
+        for rnd in range(2):
+            for (fuse, chunk, cmin) in [(3, 0, 0), (3, 128, 32), (4, 96, 16), (4, 128, 32), (4, 128, 64), (4, 192, 32), (4, 256, 64), (4, 64, 32)]:
+                sim.set_option("fuse", fuse); sim.set_option("chunk_min", cmin); sim.set_option("chunk_rows", chunk)
+                sim.upload(None); sim.run(24)
+                best = min(sim.run_timed(steps) for _ in range(2))
+                print("%5dx%-5d fuse=%d chunk=%-3d min=%-2d units=%-6d us/step %9.3f MLUPS %8.0f" % (nx, ny, fuse, chunk, cmin, sim.get_option("fuse_units"), best / steps * 1e3, nx * ny * steps / best / 1e3), flush=True)

@@ -26,7 +26,7 @@ for name, n in cases:
     with lbm_amd.LBM(p, ob) as sim:
         sim.upload(None); sim.run(64)
         best = min(sim.run_timed(steps) for _ in range(3))
-        kind = "d2q9_multi x%d" % sim.get_option("multistep") if sim.get_option("multistep") else ({0: "d2q9_step", 1: "d2q9_step2", 3: "d2q9_step3"}[sim.get_option("fuse")])
+        kind = "d2q9_multi x%d" % sim.get_option("multistep") if sim.get_option("multistep") else ({0: "d2q9_step", 1: "d2q9_step2", 3: "d2q9_step3", 4: "d2q9_step4"}[sim.get_option("fuse")])
     us = best / steps * 1e3
     mlups = p.nx * p.ny * steps / best / 1e3
     ref = ""

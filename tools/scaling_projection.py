@@ -21,7 +21,7 @@ def rate(nx, rows, steps, ring):
     with lbm_amd.LBM(p, ob, **kw) as sim:
         sim.upload(None); sim.run(48)
         ms = min(sim.run_timed(steps) for _ in range(3))
-        kern = "multi x%d" % sim.get_option("multistep") if sim.get_option("multistep") else {0: "step", 1: "step2", 3: "step3"}[sim.get_option("fuse")]
+        kern = "multi x%d" % sim.get_option("multistep") if sim.get_option("multistep") else {0: "step", 1: "step2", 3: "step3", 4: "step4"}[sim.get_option("fuse")]
     return ms / steps * 1e3, kern
 
 

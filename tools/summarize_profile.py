@@ -58,7 +58,7 @@ with open(os.path.join(G, "prof_%s_stats" % tag, "stats_kernel_stats.csv")) as f
             avg_ns = float(r["AverageNs"])
             lines.append("kernel-trace: %s calls=%s average=%.1f us" % (r["Name"], r["Calls"], avg_ns / 1e3))
 nx, ny = (int(v) for v in workload.split("x"))
-per_launch = 3 if "step3" in step_kernel else (2 if "step2" in step_kernel else 1)
+per_launch = 4 if "step4" in step_kernel else (3 if "step3" in step_kernel else (2 if "step2" in step_kernel else 1))
 fused = per_launch > 1
 alg = 72.0 * nx * ny * per_launch
 lines += ["", "dominant kernel: %s (%d timestep(s) per launch)" % (step_kernel, per_launch), "step kernel, %s: FETCH_SIZE %.6g KiB (x2 on gfx950), WRITE_SIZE %.6g KiB" % (workload, step_fetch, step_write),
@@ -70,6 +70,6 @@ open(os.path.join(P, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + 
 print("\n".join(lines))
 tj_path = os.path.join(P, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-tj[workload + {1: "/step1", 2: "/step2", 3: "/step3"}[per_launch]] = {"hbm_bytes_per_launch": round(hbm), "fetch_size_kib": step_fetch, "write_size_kib": step_write,
+tj[workload + "/step%d" % per_launch] = {"hbm_bytes_per_launch": round(hbm), "fetch_size_kib": step_fetch, "write_size_kib": step_write,
                 "source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)" % tag}
 json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
