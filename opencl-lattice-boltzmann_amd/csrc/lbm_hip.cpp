@@ -157,7 +157,7 @@ struct lbm_ctx {
   bool halo_mode = false;   // slabs carry halo rows and exchange them (more than one slab, or forced for tests)
   int rows_min = 0;         // smallest slab of the partition (ny / nslabs): every rank takes the size-dependent
                             // decisions (kernel, halo depth, schedule) from it, so that all ranks take the same ones
-  int halo_depth = 3;       // rows exchanged per side and launch set: 3 (three-step kernel; 2 for very thin slabs) or 8
+  int halo_depth = 3;       // rows exchanged per side and launch set: 4 / 3 (four- / three-step kernel; 2 for very thin slabs) or 8
                             // (LDS multi-step kernel, small slabs)
   int rank = 0;
   int cur = 0;              // index of the grid holding the current state
@@ -244,7 +244,7 @@ int fuse_level(const lbm_ctx *c) {
     const long cells = (long)c->p.nx * c->rows_min;
     lvl = cells >= (8L << 20) ? 4 : (cells > 700L * 1024 ? 3 : 2);
   }
-  if (lvl == 4 && (c->halo_mode || !windows_in_lds(c))) lvl = 3;  // four steps per launch: one slab, LDS windows
+  if (lvl == 4 && ((c->halo_mode && c->halo_depth < 4) || !windows_in_lds(c))) lvl = 3;  // needs 4 halo rows, LDS windows
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
   return lvl;
 }
@@ -374,6 +374,10 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     int c3max = c->chunk_rows > 0 ? c->chunk_rows : (w_lds ? 16 : (c->rows_min >= 2048 ? 64 : 32));
     c3max = std::max(4, std::min(c3max, s.rows));
     const int c3min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (!w_lds && c->rows_min >= 2048 ? 8 : 6), c3max));
+    // d2q9_step4: twelve redundant intermediate rows per chunk -> long chunks (tools/ab_step4b.py, 8192x8192:
+    // 32/8 247, 64/16 253, 128/32 255 GLUPS; 16384x16384: 32/8 260, 64/16 269, 128/32 273)
+    const int c4max = std::max(4, std::min(c->chunk_rows > 0 ? c->chunk_rows : 128, s.rows));
+    const int c4min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : 32, c4max));
     if (multi) {
       // the two edge chunks hold the rows the neighbours need (2 each); the interior is everything else
       // (edge chunks are as short as the exchange allows — 2 rows when the halo depth is 2: an edge unit is one
@@ -405,19 +409,16 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       if (i1 > i0) {
         if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main)) return rc;
         if (int rc = fuse_schedule(s, i0, i1, c3max, c3min, true, s.f3_main, step3_sched_waves(c))) return rc;
+        if (int rc = fuse_schedule(s, i0, i1, c4max, c4min, true, s.f4_main, 2)) return rc;
       } else {
-        s.f_main.units = s.f3_main.units = 0;
+        s.f_main.units = s.f3_main.units = s.f4_main.units = 0;
       }
-      s.nb_total = std::max(s.nb_total, std::max(s.f_main.units, s.f3_main.units) + e.units);
+      s.nb_total = std::max(s.nb_total, std::max(s.f_main.units, std::max(s.f3_main.units, s.f4_main.units)) + e.units);
     } else {
       if (int rc = fuse_schedule(s, 0, s.rows, cmax, cmin, true, s.f_main)) return rc;
       s.nb_total = std::max(s.nb_total, s.f_main.units);
       if (int rc = fuse_schedule(s, 0, s.rows, c3max, c3min, true, s.f3_main, step3_sched_waves(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f3_main.units);
-      // d2q9_step4: twelve redundant intermediate rows per chunk -> long chunks (tools/ab_step4b.py, 8192x8192:
-      // 32/8 247, 64/16 253, 128/32 255 GLUPS; 16384x16384: 32/8 260, 64/16 269, 128/32 273)
-      const int c4max = std::max(4, std::min(c->chunk_rows > 0 ? c->chunk_rows : 128, s.rows));
-      const int c4min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : 32, c4max));
       if (int rc = fuse_schedule(s, 0, s.rows, c4max, c4min, true, s.f4_main, 2)) return rc;
       s.nb_total = std::max(s.nb_total, s.f4_main.units);
     }
@@ -531,6 +532,14 @@ void launch_step3(const lbm_ctx *c, const Step2Args &a, float *partials3, int un
   else if (lds) launch_step3_v<true, 2>(ntl, a, partials3, units, st);
   else if (one) launch_step3_v<false, 1>(ntl, a, partials3, units, st);
   else launch_step3_v<false, 2>(ntl, a, partials3, units, st);
+}
+
+void launch_step4(const lbm_ctx *c, const Step2Args &a, float *partials3, float *partials4, int units, hipStream_t st) {
+  const int ntl = c->nt_loads >= 0 ? c->nt_loads : 0;
+  const dim3 grid(units), block(64);
+  if (ntl == 2) hipLaunchKernelGGL((d2q9_step4<true, 2>), grid, block, 0, st, a, partials3, partials4);
+  else if (ntl == 1) hipLaunchKernelGGL((d2q9_step4<true, 1>), grid, block, 0, st, a, partials3, partials4);
+  else hipLaunchKernelGGL((d2q9_step4<true, 0>), grid, block, 0, st, a, partials3, partials4);
 }
 
 MultiArgs base_args_multi(const lbm_ctx *c, const Slab &s, int src, int T, bool accel_next) {
@@ -672,7 +681,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       int used = s.nb_main + s.nb_edge;
       if (batch_kind == KIND_FUSED2) used = s.f_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED3) used = s.f3_main.units + (multi ? s.f_edge.units : 0);
-      if (batch_kind == KIND_FUSED4) used = s.f4_main.units;
+      if (batch_kind == KIND_FUSED4) used = s.f4_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_MULTI) used = s.m_tiles_x * s.m_tiles_y;
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
@@ -726,11 +735,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           a.partials1 = slot1;
           a.partials2 = slot2;
           float *slot3 = slot2 + s.nb_total;
-          const int ntl = c->nt_loads >= 0 ? c->nt_loads : 0;
-          const dim3 grid(s.f4_main.units), block(64);
-          if (ntl == 2) hipLaunchKernelGGL((d2q9_step4<true, 2>), grid, block, 0, s.s_main, a, slot3, slot3 + s.nb_total);
-          else if (ntl == 1) hipLaunchKernelGGL((d2q9_step4<true, 1>), grid, block, 0, s.s_main, a, slot3, slot3 + s.nb_total);
-          else hipLaunchKernelGGL((d2q9_step4<true, 0>), grid, block, 0, s.s_main, a, slot3, slot3 + s.nb_total);
+          launch_step4(c, a, slot3, slot3 + s.nb_total, s.f4_main.units, s.s_main);
         } else if (kind == KIND_FUSED3) {
           Step2Args a = base_args2(c, s, src, !last, s.f3_main);
           a.partials1 = slot1;
@@ -771,6 +776,21 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           mm.partials = slot1;
           mm.ty_begin = 1; mm.ty_split = int_trows; mm.ty_begin2 = 0;
           launch_multi(s, mm, int_trows, s.s_main);
+          HIP_TRY(hipGetLastError());
+        }
+      } else if (kind == KIND_FUSED4) {
+        float *slot3 = slot2 + s.nb_total, *slot4 = slot3 + s.nb_total;
+        Step2Args e = base_args2(c, s, src, !last, s.f_edge);
+        e.skip_chunk = s.f_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
+        e.partials1 = slot1 + s.f4_main.units;
+        e.partials2 = slot2 + s.f4_main.units;
+        launch_step4(c, e, slot3 + s.f4_main.units, slot4 + s.f4_main.units, s.f_edge.units, s.s_edge);
+        HIP_TRY(hipGetLastError());
+        if (s.f4_main.units > 0) {
+          Step2Args m = base_args2(c, s, src, !last, s.f4_main);
+          m.partials1 = slot1;
+          m.partials2 = slot2;
+          launch_step4(c, m, slot3, slot4, s.f4_main.units, s.s_main);
           HIP_TRY(hipGetLastError());
         }
       } else if (kind == KIND_FUSED3) {
@@ -1020,8 +1040,9 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     const int rows_min = params->ny / nslabs_global;
     c->rows_min = rows_min;
     const bool small = (long)params->nx * rows_min <= 540L * 1024;
-    // ... and big slabs depth 3, what the three-steps-per-launch kernel needs
-    c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : (rows_min >= 6 ? 3 : 2);
+    // ... slabs of 8M cells and more depth 4 (four-steps-per-launch kernel), the others depth 3 (three-step kernel)
+    const bool big = (long)params->nx * rows_min >= (8L << 20);
+    c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : (big ? 4 : (rows_min >= 6 ? 3 : 2));
     if (const char *hd = getenv("LBM_HALO_DEPTH")) c->halo_depth = std::max(2, std::min(kMultiMaxT, atoi(hd)));
     if (rows_min < 2 * c->halo_depth) c->halo_depth = 2;
   }
@@ -1354,7 +1375,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
-  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units) + c->slabs[0].f_edge.units);
+  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;
   else return fail(LBM_ERR_ARG, "unknown option '%s'", key);

@@ -28,7 +28,7 @@ with lbm_amd.LBM(p, ob) as sim:
 
 os.environ["LBM_FORCE_HALO"] = "1"
 os.environ["LBM_TRANSPORT"] = transport
-for (fuse, ms) in ((0, 0), (1, 0), (3, 0), (0, 8), (0, 5)):  # 1 / 2 / 3 / 8 / 5 timesteps per launch set (halo depth 8)
+for (fuse, ms) in ((0, 0), (1, 0), (3, 0), (4, 0), (0, 8), (0, 5)):  # 1 / 2 / 3 / 4 / 8 / 5 timesteps per launch set (halo depth 8)
     kw = dict(rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) if transport == "rccl" else dict(devices=[0])
     with lbm_amd.LBM(p, ob, **kw) as sim:
         assert sim.get_option("transport") == (1 if transport == "rccl" else 2)

@@ -304,6 +304,30 @@ def test_rccl_transport_self_ring(transport):
     assert "self-ring ok" in r.stdout
 
 
+@pytest.mark.parametrize("nslabs,ny", [(2, 50), (3, 50), (2, 16), (4, 67), (5, 128), (2, 260)])
+def test_row_slabs_four_steps_per_launch(lbm, nslabs, ny, monkeypatch):
+    """slabs with halo depth 4 (what slabs of 8M cells and more get) and d2q9_step4 on edge + interior launches:
+    bit-identical to one slab; 37 steps = nine full launch sets + one leftover step"""
+    monkeypatch.setenv("LBM_HALO_DEPTH", "4")
+    rng = np.random.default_rng(6)
+    nx, nsteps = 256, 37
+    ob, cells0 = random_case(rng, nx, ny)
+    ob[0, :] = 0
+    ob[-1, :] = 0
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob, devices=[0] * nslabs) as sim:
+        sim.set_option("multistep", 0)
+        sim.set_option("fuse", 4)
+        # slabs thinner than 8 rows fall back to halo depth 2 and the two-step kernel
+        assert sim.get_option("fuse") == (4 if ny // nslabs >= 8 else 1)
+        sim.upload(cells0)
+        sim.run(nsteps)
+        many, av_many = sim.download()
+    assert np.array_equal(one, many)
+    assert max_rel(av_many, av_one) < 2e-6
+
+
 def test_row_slabs_large_fused(lbm):
     """2048x512 over 4 slabs with the two-step kernel's edge/interior split and tapered schedule"""
     rng = np.random.default_rng(9)
