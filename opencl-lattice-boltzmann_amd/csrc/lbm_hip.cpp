@@ -271,10 +271,13 @@ int multistep_effective(const lbm_ctx *c) {
 // 8192x8192).  The schedule therefore tapers: every band (the share of one XCD) starts with chunks of
 // `cmax` rows and ends with ever shorter ones (guided self-scheduling), down to `cmin`.  (R full rounds of equal
 // chunks instead of the taper: within +-2 % on 8192x1024 ... 8192x8192, no consistent sign — not adopted.)
-int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g, int waves_per_simd = 2) {
+int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g, int waves_per_simd = 2,
+                  int reserve = 0) {
   const int rows = r1 - r0;
   g.nbands = (allow_bands && rows >= 8 * 4 * cmin) ? 8 : 1;
-  const int waves_resident = 256 * 4 * waves_per_simd;  // CUs x SIMDs x waves per SIMD the kernel's registers allow
+  // CUs x SIMDs x waves per SIMD the kernel's registers / LDS allow, minus the wave slots a concurrent launch needs
+  // (slab mode: the edge launch, which must find its slots at once — see slab_geometry)
+  const int waves_resident = std::max(256, 256 * 4 * waves_per_simd - reserve);
   const double slots = std::max(1.0, (double)waves_resident / g.nbands / s.strips);  // concurrent chunks per band
   std::vector<int> starts;
   int chunks_per_band = 0;
@@ -407,9 +410,14 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       e.units = e.units_per_band;
       const int i0 = s.row0 + s.edge_rows, i1 = s.row0 + s.rows - s.edge_rows;
       if (i1 > i0) {
-        if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main)) return rc;
-        if (int rc = fuse_schedule(s, i0, i1, c3max, c3min, true, s.f3_main, step3_sched_waves(c))) return rc;
-        if (int rc = fuse_schedule(s, i0, i1, c4max, c4min, true, s.f4_main, 2)) return rc;
+        // The interior launch leaves the edge launch its wave slots: an interior schedule that fills all 2048 slots
+        // in one round of equal units starves the edge workgroups that were not dispatched first until other EDGE
+        // workgroups retire (kernel trace, 8192x1024 slab, d2q9_step4: edge kernel 140 us instead of 50, and with
+        // the exchange behind it the critical path of the launch set)
+        const int rsv = (e.nchunks - 1) * s.strips;  // the edge units that do work (those of the skipped chunk exit at once)
+        if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main, 2, rsv)) return rc;
+        if (int rc = fuse_schedule(s, i0, i1, c3max, c3min, true, s.f3_main, step3_sched_waves(c), rsv)) return rc;
+        if (int rc = fuse_schedule(s, i0, i1, c4max, c4min, true, s.f4_main, 2, rsv)) return rc;
       } else {
         s.f_main.units = s.f3_main.units = s.f4_main.units = 0;
       }

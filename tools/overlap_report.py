@@ -8,7 +8,7 @@ iv = {"interior": [], "edge": [], "rccl": []}
 for r in rows:
     name, st, en = r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
-    if "d2q9_step2" in name or "d2q9_step3" in name or "d2q9_multi" in name:
+    if "d2q9_step2" in name or "d2q9_step3" in name or "d2q9_step4" in name or "d2q9_multi" in name:
         iv["pending"] = iv.get("pending", []) + [(st, en, grid)]
     elif "nccl" in name.lower() or "rccl" in name.lower():
         iv["rccl"].append((st, en))
