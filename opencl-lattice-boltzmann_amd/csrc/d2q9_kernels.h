@@ -425,6 +425,43 @@ __device__ __forceinline__ void issue_row_loads(const Step2Args &a, int r, int x
   }
 }
 
+// The same loads written as (wave-uniform row pointer) + (32-bit unsigned byte offset of the lane): the shape the
+// SGPR-base addressing mode of global_load takes — no 64-bit vector address per access, six VGPRs fewer.  Worth
+// nothing in d2q9_step3 (tools/ab_step3.py), but d2q9_step4 sits at the 256-register limit, where every register
+// that is not spilled counts.
+__device__ __forceinline__ const float *at_byte(const float *uniform_base, unsigned byte_off) {
+  return reinterpret_cast<const float *>(reinterpret_cast<const char *>(uniform_base) + byte_off);
+}
+template <bool NTL>
+__device__ __forceinline__ void issue_row_loads_sbase(const Step2Args &a, int r, int xcol, int xhalo_w, int xhalo_e, int lane,
+                                                      RowLoads &in) {
+  const size_t ps = a.plane_stride, rs = a.row_stride;
+  const int r_s = (r == 0) ? a.ny - 1 : r - 1;
+  const int r_n = (r == a.ny - 1) ? 0 : r + 1;
+  const float *Rc = a.src + (size_t)r * rs, *Rs = a.src + (size_t)r_s * rs, *Rn = a.src + (size_t)r_n * rs;
+  unsigned xb = (unsigned)xcol * 4u;
+  // keeps the 32->64-bit extension of the offset next to its uses: instruction selection works per basic block and
+  // only then recognises base + zext(offset) as the SGPR-base addressing mode
+  asm volatile("" : "+v"(xb));
+  in.c[0] = load4<NTL>(at_byte(Rc, xb));
+  in.c[1] = load4<NTL>(at_byte(Rc + 1 * ps, xb));
+  in.c[3] = load4<NTL>(at_byte(Rc + 3 * ps, xb));
+  in.c[2] = load4<NTL>(at_byte(Rs + 2 * ps, xb));
+  in.c[5] = load4<NTL>(at_byte(Rs + 5 * ps, xb));
+  in.c[6] = load4<NTL>(at_byte(Rs + 6 * ps, xb));
+  in.c[4] = load4<NTL>(at_byte(Rn + 4 * ps, xb));
+  in.c[7] = load4<NTL>(at_byte(Rn + 7 * ps, xb));
+  in.c[8] = load4<NTL>(at_byte(Rn + 8 * ps, xb));
+  in.m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)r * a.nx + xcol);
+  in.h0 = in.h1 = in.h2 = 0.f;
+  if (lane == 0 || lane == 63) {
+    const bool lo = (lane == 0);
+    in.h0 = lo ? Rc[1 * ps + xhalo_w] : Rc[3 * ps + xhalo_e];
+    in.h1 = lo ? Rs[5 * ps + xhalo_w] : Rs[6 * ps + xhalo_e];
+    in.h2 = lo ? Rn[8 * ps + xhalo_w] : Rn[7 * ps + xhalo_e];
+  }
+}
+
 // shifts a float4-per-lane plane by one cell: result[v] = value at x-1 (west) or x+1 (east)
 __device__ __forceinline__ void shift_from_west(const float (&p)[4], float halo, float (&out)[4]) {
   out[0] = dpp_from_lane_below(p[3], halo); out[1] = p[0]; out[2] = p[1]; out[3] = p[2];
@@ -796,13 +833,16 @@ __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *parti
 }
 
 // ---- four timesteps per launch ------------------------------------------------------------------------
-// d2q9_step3 with one more level: windows 1 and 2 in LDS as before (18 KB per wave is all the LDS two waves per SIMD
-// leave), window 3 in the registers that kernel leaves free.  Level-1 rows k = 0 .. n+5 (row r0 + k*d), level-2 row
+// d2q9_step3 with one more level: windows 1 and 2 in LDS as before, window 3 in the registers that kernel leaves free.  Level-1 rows k = 0 .. n+5 (row r0 + k*d), level-2 row
 // k-1 from k = 2, level-3 row k-2 from k = 4, output row k-3 from k = 6.  One cell of the outermost lane becomes
 // invalid per level, so the two halo lanes per side of d2q9_step3 are enough here too (60 output lanes).
+// Two planes of window 3 go to the 2 KB of LDS per wave that two waves per SIMD leave free (8 x 20 KB = the CU's
+// 160 KB), and the row loads use SGPR-base addressing: together they bring the kernel from 254 VGPRs + 12 spilled
+// to 253 and none.  The spills cost 17 % (8192x8192: 249 -> 274 GLUPS with the LDS planes, -> 291 with both).
+constexpr int kW3Lds = 2;
 template <bool NT, int NTL = 0>
 __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *partials3, float *partials4) {
-  __shared__ v4f win[2 * kWinSlots * 64];
+  __shared__ v4f win[(2 * kWinSlots + kW3Lds) * 64];
   const int lane = threadIdx.x;
   const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
   if (slot >= a.units_per_band) return;
@@ -830,12 +870,12 @@ __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *pa
   const int r0 = up ? ys - 3 : ye + 2;
 
   float sum1 = 0.f, sum2 = 0.f, sum3 = 0.f, sum4 = 0.f;
-  v4f *const lw1 = win + lane, *const lw2 = win + kWinSlots * 64 + lane;
+  v4f *const lw1 = win + lane, *const lw2 = win + kWinSlots * 64 + lane, *const lw3 = win + 2 * kWinSlots * 64 + lane;
   Window w3;
   uint32_t m_mid1 = 0, m_mid2 = 0, m_mid3 = 0;
   float top1[9][4], top2[9][4], top3[9][4];
   RowLoads in;
-  issue_row_loads<NTL == 1>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, in);
+  issue_row_loads_sbase<NTL == 1>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, in);
 #pragma unroll
   for (int v = 0; v < 4; v++) {
 #pragma unroll
@@ -850,8 +890,8 @@ __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *pa
     const uint32_t m1 = in.m;
     if (owner && k >= 3 && k <= n + 2) sum1 += t1;
     if (k + 1 <= n + 5) {
-      if (NTL == 2 && k + 1 >= 6 && k + 1 <= n - 1) issue_row_loads<true>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
-      else issue_row_loads<NTL == 1>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      if (NTL == 2 && k + 1 >= 6 && k + 1 <= n - 1) issue_row_loads_sbase<true>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      else issue_row_loads_sbase<NTL == 1>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
     }
     uint32_t m2 = 0, m3 = 0;
     if (k >= 2) {
@@ -879,6 +919,7 @@ __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *pa
     if (k >= 6) {
       const int y = r0 + (k - 3) * d;
       float g[9][4], o[9][4];
+      if (kW3Lds == 2) { lds_get(lw3, 0, w3.mid[0]); lds_get(lw3, 1, w3.mid[1]); }
       window_gather(w3, top3, up, g);
       const float t4 = collide4(g, m_mid3, a.omega, (y == a.accel_row || y == a.accel_row_b) && a.accel_next, a.aw1, a.aw2, o);
       if (owner) {
@@ -890,6 +931,7 @@ __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *pa
     }
     if (k >= 4) {
       window_rotate(w3, top3, m3, up);
+      if (kW3Lds == 2) { lds_put(lw3, 0, w3.mid[0]); lds_put(lw3, 1, w3.mid[1]); }
       m_mid3 = m3;
     }
   }

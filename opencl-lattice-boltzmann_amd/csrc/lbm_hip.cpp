@@ -239,10 +239,11 @@ int fuse_level(const lbm_ctx *c) {
     // to the LDS tile kernel (multistep_effective); 768x512 88 / 83, 1024x512 82 / 81, 768x768 89 / 89 -> two steps
     // per launch; 1024x768 106 / 111, 1024x1024 114 / 118, 1536x1024 127 / 147, 2048x2048 128 / 174,
     // 4096x4096 151 / 213, 8192x8192 156 / 229 -> three steps per launch
-    // ... and four steps per launch from 8M cells up on one slab (tools/ab_step4d.py, three / four steps: 3072x2048 196 /
-    // 195, 4096x2048 205 / 208, 4096x3072 214 / 222, 4096x4096 217 / 232, 8192x8192 232 / 251, 16384x16384 240 / 275)
+    // ... and four steps per launch from 2M cells up (tools/ab_step4d.py, three / four steps: 1024x1024 120 / 114,
+    // 1536x1024 151 / 147, 2048x1024 156 / 164, 2048x2048 188 / 216, 4096x2048 205 / 252, 4096x4096 219 / 275,
+    // 8192x1024 206 / 246, 8192x8192 235 / 298)
     const long cells = (long)c->p.nx * c->rows_min;
-    lvl = cells >= (8L << 20) ? 4 : (cells > 700L * 1024 ? 3 : 2);
+    lvl = cells >= (2L << 20) ? 4 : (cells > 700L * 1024 ? 3 : 2);
   }
   if (lvl == 4 && ((c->halo_mode && c->halo_depth < 4) || !windows_in_lds(c))) lvl = 3;  // needs 4 halo rows, LDS windows
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
@@ -377,10 +378,11 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     int c3max = c->chunk_rows > 0 ? c->chunk_rows : (w_lds ? 16 : (c->rows_min >= 2048 ? 64 : 32));
     c3max = std::max(4, std::min(c3max, s.rows));
     const int c3min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (!w_lds && c->rows_min >= 2048 ? 8 : 6), c3max));
-    // d2q9_step4: twelve redundant intermediate rows per chunk -> long chunks (tools/ab_step4b.py, 8192x8192:
-    // 32/8 247, 64/16 253, 128/32 255 GLUPS; 16384x16384: 32/8 260, 64/16 269, 128/32 273)
-    const int c4max = std::max(4, std::min(c->chunk_rows > 0 ? c->chunk_rows : 128, s.rows));
-    const int c4min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : 32, c4max));
+    // d2q9_step4: twelve redundant intermediate rows per chunk -> longer chunks (tools/ab_step4d.py, chunks 16/6,
+    // 32/8, 64/16, 128/32: 8192x8192 288 / 299 / 298 / 295 GLUPS, 4096x4096 247 / 252 / 275 / 275, 8192x1024
+    // 223 / 246 / 246 / 246)
+    const int c4max = std::max(4, std::min(c->chunk_rows > 0 ? c->chunk_rows : 64, s.rows));
+    const int c4min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : 16, c4max));
     if (multi) {
       // the two edge chunks hold the rows the neighbours need (2 each); the interior is everything else
       // (edge chunks are as short as the exchange allows — 2 rows when the halo depth is 2: an edge unit is one
@@ -1048,8 +1050,8 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     const int rows_min = params->ny / nslabs_global;
     c->rows_min = rows_min;
     const bool small = (long)params->nx * rows_min <= 540L * 1024;
-    // ... slabs of 8M cells and more depth 4 (four-steps-per-launch kernel), the others depth 3 (three-step kernel)
-    const bool big = (long)params->nx * rows_min >= (8L << 20);
+    // ... slabs of 2M cells and more depth 4 (four-steps-per-launch kernel), the others depth 3 (three-step kernel)
+    const bool big = (long)params->nx * rows_min >= (2L << 20);
     c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : (big ? 4 : (rows_min >= 6 ? 3 : 2));
     if (const char *hd = getenv("LBM_HALO_DEPTH")) c->halo_depth = std::max(2, std::min(kMultiMaxT, atoi(hd)));
     if (rows_min < 2 * c->halo_depth) c->halo_depth = 2;

@@ -148,7 +148,7 @@ def test_default_kernel_choice_by_grid_size(lbm):
     """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel in between, three-step kernel for
     bandwidth-bound ones"""
     expect = {(128, 128): (8, 0), (256, 256): (8, 0), (512, 512): (8, 0), (1024, 512): (0, 1), (768, 768): (0, 1),
-              (1024, 1024): (0, 3), (1536, 1024): (0, 3), (2048, 1024): (0, 3), (3072, 2048): (0, 3), (4096, 2048): (0, 4), (128, 8192): (0, 0)}
+              (1024, 1024): (0, 3), (1536, 1024): (0, 3), (2048, 1024): (0, 4), (3072, 2048): (0, 4), (4096, 2048): (0, 4), (128, 8192): (0, 0)}
     for (nx, ny), (ms, fuse) in expect.items():
         ob = np.zeros((ny, nx), np.int32)
         with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
@@ -534,7 +534,7 @@ def test_bench_one_process_per_gpu_path_single_rank():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["result_ok"] is True and j["value"] > 1000
-    assert j["roofline"]["steps_per_launch"] == 3   # row slabs: the three-step kernel, whatever the size
+    assert j["roofline"]["steps_per_launch"] == 4   # 2048x1024 = 2M cells: four steps per launch, also with halo rows
 
 
 def test_abi_error_behaviour(lbm):
