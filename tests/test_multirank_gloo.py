@@ -86,7 +86,7 @@ def _rank_main(rank, world, port, size, nsteps, depth, out_dir):
 
 
 @pytest.mark.parametrize("world,size,nsteps,depth", [(2, "128x128", 40, 1), (3, "128x256", 25, 1), (2, "128x128", 21, 2),
-                                                     (2, "128x256", 27, 8), (4, "128x256", 16, 8)])
+                                                     (2, "128x256", 27, 8), (4, "128x256", 16, 8), (3, "128x256", 22, 4), (2, "128x128", 14, 3)])
 def test_row_partition_protocol_matches_undivided_run(tmp_path, world, size, nsteps, depth):
     import torch.multiprocessing as mp
     import lbm_amd
