@@ -16,9 +16,16 @@
 // segments (rows y-1, y, y+1) instead of 9 far-apart planes — measured +12 % on 8192x8192 over
 // the reference's plane-major SoA (d2q9-bgk.c:73), whose nine 256-MiB-apart streams collide in
 // the HBM channel interleave.  The C ABI still speaks the reference's float[9][ny][nx]; upload
-// and download convert with 2-D copies.  The obstacle mask is one byte per cell.  Every thread
+// converts with 2-D copies, download repacks on the device (pack_planes).  The obstacle mask is one byte per cell.  Every thread
 // owns VEC=4 consecutive cells of one row: all 9 loads and all 9 stores of a wave are whole
 // 1-KiB contiguous segments (64 lanes x 16 B).
+//
+// Kernels, by how many timesteps one launch advances (all inline the same collide_cell: bit-identical results):
+//   d2q9_step   1   thread = 4 cells, workgroup = one 1024-cell tile; the bandwidth-bound baseline
+//   d2q9_step2  2   wave = strip of 60 float4 lanes sweeping a chunk of rows; intermediate row window in registers
+//   d2q9_step3  3   the same with two windows, both in LDS (two waves per SIMD)
+//   d2q9_step4  4   a third window in registers and LDS leftovers; the default from 2M cells
+//   d2q9_multi  <=8 1024-thread workgroup on an LDS-resident tile with redundant halo; launch-bound small grids
 //
 // Not a translation of kernels.cl: different work decomposition (float4 rows, grid-stride,
 // wave64 shuffles), different arithmetic grouping (pairwise momentum differences, shared
