@@ -257,7 +257,7 @@ int multistep_effective(const lbm_ctx *c) {
   if ((long)div_up(c->p.nx, 16) * div_up(c->rows_min + 1, 8) > 65536) return 0;
   // with halo rows a launch can advance at most as many steps as the halos are deep
   const int cap = c->halo_mode ? std::min(kMultiMaxT, c->halo_depth) : kMultiMaxT;
-  if (c->halo_mode && c->halo_depth < kMultiMaxT && c->multistep < 0) return 0;  // big slabs: two-step kernel
+  if (c->halo_mode && c->halo_depth < kMultiMaxT && c->multistep < 0) return 0;  // big slabs: the register/LDS-window kernels
   if (c->multistep >= 0) return std::min(c->multistep, cap);
   // auto (profiles/r01_kernel_choice.txt, us/step LDS tiles / two-step kernel): 128x128 1.4 / 5, 384x384 3.4 / 4.2,
   // 512x512 3.9 / 4.4, 768x512 5.6 / 4.5, 1024x512 7.3 / 6.4 -> up to 300K cells on one slab.  Slabs that exchange
