@@ -340,6 +340,21 @@ def test_row_slabs_large_fused(lbm):
         assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
 
 
+def test_row_slabs_of_2m_cells_use_four_steps_and_halo_depth_4(lbm):
+    """8192x512 over 2 slabs: each slab holds 2M cells, so the library picks halo depth 4 and d2q9_step4 by itself"""
+    rng = np.random.default_rng(10)
+    nx, ny, nsteps = 8192, 512, 14
+    ob, cells0 = random_case(rng, nx, ny, blocked=0.02)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob, devices=[0, 0]) as sim:
+        assert sim.get_option("fuse") == 4 and sim.get_option("multistep") == 0
+        sim.upload(cells0)
+        sim.run(nsteps)
+        many, av_many = sim.download()
+    assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
+
+
 def test_row_slabs_split_runs_and_shipped_geometry(lbm, oracle_f32_omp):
     p, obst = lbm.read_inputs(*input_files("128x256"))  # periodic in y: rows 0 and 255 are open
     p.max_iters = 120
