@@ -128,8 +128,8 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  2 = unaligned 16-byte loads, 3 = wave64 DPP shifts, 4 = LDS-staged row with halo
  *   "fuse"         1 (or 2) = advance two timesteps per launch (intermediate state kept in registers, half
  *                  the HBM traffic), 3 = three timesteps per launch (two windows of intermediate rows, a third
- *                  of the traffic), 4 = four timesteps per launch (one slab only; falls back to 3 with row
- *                  slabs), 0 = one launch per step, -1 = auto (by grid size).
+ *                  of the traffic), 4 = four timesteps per launch (with row slabs only where the halo rows are 4
+ *                  deep — slabs of 2M cells and more — else 3), 0 = one launch per step, -1 = auto (by size).
  *   "windows"      where the three-step kernel keeps its two windows: 1 = LDS (two waves per SIMD), 0 = registers
  *                  (one wave per SIMD), -1 = auto (1)
  *   "load_bufs"    row-sets of source loads the three-step kernel keeps in flight: 1 or 2, 0 = auto
