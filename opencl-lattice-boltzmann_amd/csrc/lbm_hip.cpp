@@ -221,7 +221,14 @@ void split_rows(int ny, int P, int idx, int *y0, int *rows) {
 bool windows_in_lds(const lbm_ctx *c) { return c->windows < 0 ? kStep3LdsDefault : c->windows != 0; }
 int step3_load_bufs(const lbm_ctx *c) { return c->load_bufs > 0 ? c->load_bufs : (windows_in_lds(c) ? 1 : 2); }
 
-int step3_sched_waves(const lbm_ctx *c) { return c->sched_waves > 0 ? c->sched_waves : (windows_in_lds(c) ? 2 : 1); }
+// waves per SIMD the d2q9_step3 schedule plans for: two with the windows in LDS — except on grids of up to 800K cells,
+// where one round of 1024 longer units beats 1.5 waves per SIMD of shorter ones (tools/ab_small_mid.py, GLUPS planned
+// for 2 / 1: 1024x512 81 / 93, 768x768 90 / 102, 1280x512 97 / 100, 1024x768 112 / 112, 1024x1024 119 / 118)
+int step3_sched_waves(const lbm_ctx *c) {
+  if (c->sched_waves > 0) return c->sched_waves;
+  if (!windows_in_lds(c)) return 1;
+  return (long)c->p.nx * c->rows_min <= 800L * 1024 ? 1 : 2;
+}
 
 bool fuse_possible(const lbm_ctx *c) {
   if (!c->vec4 || c->p.nx < 256) return false;
@@ -236,14 +243,13 @@ int fuse_level(const lbm_ctx *c) {
     lvl = c->fuse == 0 ? 0 : (c->fuse >= 3 ? c->fuse : 2);
   } else {
     // auto (same-box A/B, tools/ab_mid.py + tools/ab_fuse3.py, GLUPS two-step / three-step): the smallest grids go
-    // to the LDS tile kernel (multistep_effective); 768x512 88 / 83, 1024x512 82 / 81, 768x768 89 / 89 -> two steps
-    // per launch; 1024x768 106 / 111, 1024x1024 114 / 118, 1536x1024 127 / 147, 2048x2048 128 / 174,
-    // 4096x4096 151 / 213, 8192x8192 156 / 229 -> three steps per launch
+    // to the LDS tile kernel (multistep_effective); 768x512 89 / 86 -> two steps per launch; 1024x512 82 / 93,
+    // 768x768 89 / 102, 1024x768 106 / 112, 1024x1024 114 / 119, 1536x1024 127 / 147 -> three steps per launch
     // ... and four steps per launch from 2M cells up (tools/ab_step4d.py, three / four steps: 1024x1024 120 / 114,
     // 1536x1024 151 / 147, 2048x1024 156 / 164, 2048x2048 188 / 216, 4096x2048 205 / 252, 4096x4096 219 / 275,
     // 8192x1024 206 / 246, 8192x8192 235 / 298)
     const long cells = (long)c->p.nx * c->rows_min;
-    lvl = cells >= (2L << 20) ? 4 : (cells > 700L * 1024 ? 3 : 2);
+    lvl = cells >= (2L << 20) ? 4 : (cells > 450L * 1024 ? 3 : 2);
   }
   if (lvl == 4 && ((c->halo_mode && c->halo_depth < 4) || !windows_in_lds(c))) lvl = 3;  // needs 4 halo rows, LDS windows
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;

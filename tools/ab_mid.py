@@ -9,7 +9,7 @@ for (nx, ny) in [(384, 384), (512, 512), (768, 512), (1024, 512), (768, 768), (1
     steps = max(240, int(4e8 / (nx * ny)) // 24 * 24)
     with lbm_amd.LBM(p, ob) as sim:
         row = []
-        for (ms, fuse) in [(0, 0), (0, 1), (0, 3), (4, 0), (8, 0)]:
+        for (ms, fuse) in [(0, 0), (0, 1), (0, 3), (0, 4), (8, 0)]:
             sim.set_option("fuse", fuse); sim.set_option("multistep", ms)
             sim.upload(None); sim.run(96)
             best = min(sim.run_timed(steps) for _ in range(3))
