@@ -230,6 +230,8 @@ int step3_sched_waves(const lbm_ctx *c) {
   return (long)c->p.nx * c->rows_min <= 800L * 1024 ? 1 : 2;
 }
 
+int step4_sched_waves(const lbm_ctx *c) { return c->sched_waves > 0 ? c->sched_waves : 2; }
+
 bool fuse_possible(const lbm_ctx *c) {
   if (!c->vec4 || c->p.nx < 256) return false;
   return c->rows_min >= 8;
@@ -425,7 +427,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
         const int rsv = (e.nchunks - 1) * s.strips;  // the edge units that do work (those of the skipped chunk exit at once)
         if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main, 2, rsv)) return rc;
         if (int rc = fuse_schedule(s, i0, i1, c3max, c3min, true, s.f3_main, step3_sched_waves(c), rsv)) return rc;
-        if (int rc = fuse_schedule(s, i0, i1, c4max, c4min, true, s.f4_main, 2, rsv)) return rc;
+        if (int rc = fuse_schedule(s, i0, i1, c4max, c4min, true, s.f4_main, step4_sched_waves(c), rsv)) return rc;
       } else {
         s.f_main.units = s.f3_main.units = s.f4_main.units = 0;
       }
@@ -435,7 +437,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       s.nb_total = std::max(s.nb_total, s.f_main.units);
       if (int rc = fuse_schedule(s, 0, s.rows, c3max, c3min, true, s.f3_main, step3_sched_waves(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f3_main.units);
-      if (int rc = fuse_schedule(s, 0, s.rows, c4max, c4min, true, s.f4_main, 2)) return rc;
+      if (int rc = fuse_schedule(s, 0, s.rows, c4max, c4min, true, s.f4_main, step4_sched_waves(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f4_main.units);
     }
   }
