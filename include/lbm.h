@@ -133,7 +133,10 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "windows"      where the three-step kernel keeps its two windows: 1 = LDS (two waves per SIMD), 0 = registers
  *                  (one wave per SIMD), -1 = auto (1)
  *   "load_bufs"    row-sets of source loads the three-step kernel keeps in flight: 1 or 2, 0 = auto
- *   "sched_waves"  waves per SIMD the three-step kernel's chunk schedule plans for: 1 or 2, 0 = auto
+ *   "sched_waves"  waves per SIMD the three- / four-step kernels' chunk schedule plans for: 1 or 2, 0 = auto
+ *   "pair"         chunk-pair form of the three- / four-step kernels (two chunks that start at a common boundary
+ *                  run as one workgroup and hand each other their first rows instead of computing them twice):
+ *                  1 = always, 0 = never, -1 = auto (where all units of a launch are resident at once)
  *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
  *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)

@@ -839,6 +839,133 @@ __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *parti
   }
 }
 
+// ---- three timesteps per launch, chunk pairs ------------------------------------------------------------
+// d2q9_step3 (LDS windows, one row-set of loads in flight) with the start-up redundancy removed: a workgroup is
+// TWO waves, the chunks 2p (sweeping down) and 2p+1 (sweeping up) of one strip, which START at their common
+// boundary at the same time.  What a lone wave computes redundantly to prime its windows — two first-level rows
+// and one second-level row beyond its start, the partner's first rows — the partner computes anyway: each wave
+// writes the three planes of its first first-level row (iteration 2) and of its first second-level row
+// (iteration 3) that move towards the partner straight into the `trail` slots of the partner's LDS windows,
+// where the partner's ordinary gather finds them one iteration later.  Two barriers per workgroup, no extra LDS,
+// n+2 iterations and 3n+3 collision passes per chunk of n rows instead of n+4 and 3n+6.  A wave whose partner
+// is empty or skipped runs alone exactly like d2q9_step3.  Same arithmetic, bit-identical.
+__device__ __forceinline__ void lds_put_trail(v4f *w, int par, const float (&top)[9][4], bool up) {
+  float t[4];
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[2][v] : top[4][v];
+  lds_put(w, 3 + 3 * par, t);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[5][v] : top[8][v];
+  lds_put(w, 4 + 3 * par, t);
+#pragma unroll
+  for (int v = 0; v < 4; v++) t[v] = up ? top[6][v] : top[7][v];
+  lds_put(w, 5 + 3 * par, t);
+}
+
+template <bool NT, int NTL = 0>
+__global__ __launch_bounds__(128) void d2q9_step3p(const Step2Args a, float *partials3) {
+  __shared__ v4f win[2 * 2 * kWinSlots * 64];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
+  if (slot >= a.units_per_band) return;  // units_per_band counts chunk PAIRS x strips here
+  const int punit = band * a.units_per_band + slot;
+  const int pair = punit / a.strips, strip = punit - pair * a.strips;
+  const int chunk = 2 * pair + wv;
+  const int unit = chunk * a.strips + strip;  // slot of the partial sums, as in d2q9_step3
+  const int ys = a.chunk_start[chunk];
+  const int ye = a.chunk_start[chunk + 1];
+  const int pys = a.chunk_start[chunk ^ 1], pye = a.chunk_start[(chunk ^ 1) + 1];
+  const bool empty = ys >= ye || chunk == a.skip_chunk;
+  const bool paired = !empty && pys < pye && (chunk ^ 1) != a.skip_chunk;  // the same on both waves
+  if (empty) {
+    if (lane == 0) a.partials1[unit] = a.partials2[unit] = partials3[unit] = 0.f;
+    return;  // the partner then runs alone and meets no barrier
+  }
+  const int q4 = a.nx >> 2;
+  const int qcol = strip * a.lanes_out + lane - 2;
+  const bool owner = (lane >= 2) && (lane < 2 + a.lanes_out) && (qcol < q4);
+  int qw = qcol % q4;
+  if (qw < 0) qw += q4;
+  const int xcol = qw * 4;
+  const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
+  const int xhalo_e = (xcol + 4 >= a.nx) ? 0 : xcol + 4;
+  const size_t ps = a.plane_stride;
+  auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
+
+  const bool up = wv != 0;  // even chunks sweep down from their top, odd ones up from their bottom: pairs start together
+  const int n = ye - ys;
+  const int d = up ? 1 : -1;
+  const int r0 = up ? ys - 2 : ye + 1;
+  const int kbeg = paired ? 2 : 0;   // the first own row is k = 2
+  const int k2 = paired ? 3 : 2;     // first iteration with a second-level row
+
+  float sum1 = 0.f, sum2 = 0.f, sum3 = 0.f;
+  v4f *const mine = win + wv * (2 * kWinSlots * 64) + lane, *const theirs = win + (wv ^ 1) * (2 * kWinSlots * 64) + lane;
+  v4f *const lw1 = mine, *const lw2 = mine + kWinSlots * 64;
+  uint32_t m_mid1 = 0, m_mid2 = 0;
+  float top1[9][4], top2[9][4];
+  RowLoads in;
+  issue_row_loads<NTL == 1>(a, wrap(r0 + kbeg * d), xcol, xhalo_w, xhalo_e, lane, in);
+  for (int k = kbeg; k <= n + 3; k++) {
+    const int par = k & 1;
+    const int row1 = wrap(r0 + k * d);
+    const float t1 = first_step_row(a, in, row1, top1);
+    const uint32_t m1 = in.m;
+    if (owner && k >= 2 && k <= n + 1) sum1 += t1;
+    if (k + 1 <= n + 3) {
+      if (NTL == 2 && k + 1 >= 4 && k + 1 <= n - 1) issue_row_loads<true>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      else issue_row_loads<NTL == 1>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    }
+    uint32_t m2 = 0;
+    if (k >= k2) {
+      const int row2 = wrap(r0 + (k - 1) * d);
+      float g[9][4];
+      lds_window_gather(lw1, par, top1, up, g);
+      m2 = m_mid1;
+      const float t2 = collide4(g, m2, a.omega, row2 == a.accel_row || row2 == a.accel_row_b, a.aw1, a.aw2, top2);
+      if (owner && k >= 3 && k <= n + 2) sum2 += t2;
+    }
+    lds_window_put(lw1, par, top1, up);
+    m_mid1 = m1;
+    if (paired && k == 2) {
+      // my first first-level row is the row just across the partner's start: its planes moving the partner's way are
+      // what the partner's gather of iteration 3 expects in the trail slots of its window 1 (parity 1)
+      lds_put_trail(theirs, 1, top1, !up);
+      __syncthreads();
+    }
+    if (k >= 4) {
+      const int y = r0 + (k - 2) * d;
+      float g[9][4], o[9][4];
+      lds_window_gather(lw2, par, top2, up, g);
+      const float t3 = collide4(g, m_mid2, a.omega, (y == a.accel_row || y == a.accel_row_b) && a.accel_next, a.aw1, a.aw2, o);
+      if (owner) {
+        sum3 += t3;
+        float *dp = a.dst + (size_t)y * a.row_stride + xcol;
+#pragma unroll
+        for (int kk = 0; kk < 9; kk++) store4<NT>(dp + kk * ps, o[kk][0], o[kk][1], o[kk][2], o[kk][3]);
+      }
+    }
+    if (k >= k2) {
+      lds_window_put(lw2, par, top2, up);
+      m_mid2 = m2;
+    }
+    if (paired && k == 3) {
+      // the same one level up: my first second-level row into the trail slots (parity 0) of the partner's window 2
+      lds_put_trail(theirs + kWinSlots * 64, 0, top2, !up);
+      __syncthreads();
+    }
+  }
+  sum1 = wave_sum(sum1);
+  sum2 = wave_sum(sum2);
+  sum3 = wave_sum(sum3);
+  if (lane == 0) {
+    a.partials1[unit] = sum1;
+    a.partials2[unit] = sum2;
+    partials3[unit] = sum3;
+  }
+}
+
 // ---- four timesteps per launch ------------------------------------------------------------------------
 // d2q9_step3 with one more level: windows 1 and 2 in LDS as before, window 3 in the registers that kernel leaves free.  Level-1 rows k = 0 .. n+5 (row r0 + k*d), level-2 row
 // k-1 from k = 2, level-3 row k-2 from k = 4, output row k-3 from k = 6.  One cell of the outermost lane becomes
@@ -942,6 +1069,159 @@ __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *pa
       m_mid3 = m3;
     }
   }
+  sum1 = wave_sum(sum1);
+  sum2 = wave_sum(sum2);
+  sum3 = wave_sum(sum3);
+  sum4 = wave_sum(sum4);
+  if (lane == 0) {
+    a.partials1[unit] = sum1;
+    a.partials2[unit] = sum2;
+    partials3[unit] = sum3;
+    partials4[unit] = sum4;
+  }
+}
+
+// ---- four timesteps per launch, chunk pairs -------------------------------------------------------------
+// d2q9_step4 with the start-up redundancy removed the way d2q9_step3p does it: the chunks 2p (down) and 2p+1 (up) of a
+// strip start at their common boundary as one workgroup of two waves and hand each other their first row of every
+// level — levels 1 and 2 into the trail slots of the partner's LDS windows (iterations 3 and 4), level 3 through
+// the partner's window-2 trail slots once its own level-3 gather has consumed them (iteration 5, two barriers) and
+// from there into the register window.  n+3 iterations and 4n+6 collision passes per chunk instead of n+6 and 4n+12.
+template <bool NT, int NTL = 0>
+__global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *partials3, float *partials4) {
+  constexpr int kWave = (2 * kWinSlots + kW3Lds) * 64;  // LDS float4s per wave
+  __shared__ v4f win[2 * kWave];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
+  if (slot >= a.units_per_band) return;  // units_per_band counts chunk PAIRS x strips here
+  const int punit = band * a.units_per_band + slot;
+  const int pair = punit / a.strips, strip = punit - pair * a.strips;
+  const int chunk = 2 * pair + wv;
+  const int unit = chunk * a.strips + strip;
+  const int ys = a.chunk_start[chunk];
+  const int ye = a.chunk_start[chunk + 1];
+  const int pys = a.chunk_start[chunk ^ 1], pye = a.chunk_start[(chunk ^ 1) + 1];
+  const bool empty = ys >= ye || chunk == a.skip_chunk;
+  const bool paired = !empty && pys < pye && (chunk ^ 1) != a.skip_chunk;  // the same on both waves
+  if (empty) {
+    if (lane == 0) a.partials1[unit] = a.partials2[unit] = partials3[unit] = partials4[unit] = 0.f;
+    return;
+  }
+  const int q4 = a.nx >> 2;
+  const int qcol = strip * a.lanes_out + lane - 2;
+  const bool owner = (lane >= 2) && (lane < 2 + a.lanes_out) && (qcol < q4);
+  int qw = qcol % q4;
+  if (qw < 0) qw += q4;
+  const int xcol = qw * 4;
+  const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
+  const int xhalo_e = (xcol + 4 >= a.nx) ? 0 : xcol + 4;
+  const size_t ps = a.plane_stride;
+  auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
+  const bool up = wv != 0;
+  const int n = ye - ys;
+  const int d = up ? 1 : -1;
+  const int r0 = up ? ys - 3 : ye + 2;
+
+  float sum1 = 0.f, sum2 = 0.f, sum3 = 0.f, sum4 = 0.f;
+  v4f *const mine = win + wv * kWave + lane, *const theirs = win + (wv ^ 1) * kWave + lane;
+  v4f *const lw1 = mine, *const lw2 = mine + kWinSlots * 64, *const lw3 = mine + 2 * kWinSlots * 64;
+  Window w3;
+  uint32_t m_mid1 = 0, m_mid2 = 0, m_mid3 = 0;
+  float top1[9][4], top2[9][4], top3[9][4];
+  RowLoads in;
+  issue_row_loads_sbase<NTL == 1>(a, wrap(r0 + (paired ? 3 : 0) * d), xcol, xhalo_w, xhalo_e, lane, in);
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) w3.trail[k][v] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) w3.mid[k][v] = 0.f;
+  }
+  // One iteration.  PHASE 0 = the steady loop (and the whole sweep of a wave without partner: levels switch on at
+  // k = 2, 4, 6); PHASE 3, 4, 5 = the three start-up iterations of a pair, peeled so that their hand-overs do not
+  // lengthen any live range inside the steady loop (the kernel has no register to spare).
+  auto iter = [&](const int k, const int PHASE) __attribute__((always_inline)) {
+    const int par = k & 1;
+    const int row1 = wrap(r0 + k * d);
+    const float t1 = first_step_row(a, in, row1, top1);
+    const uint32_t m1 = in.m;
+    if (owner && k >= 3 && k <= n + 2) sum1 += t1;
+    if (k + 1 <= n + 5) {
+      if (NTL == 2 && k + 1 >= 6 && k + 1 <= n - 1) issue_row_loads_sbase<true>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      else issue_row_loads_sbase<NTL == 1>(a, wrap(r0 + (k + 1) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    }
+    uint32_t m2 = 0, m3 = 0;
+    if (PHASE == 0 ? k >= 2 : PHASE >= 4) {
+      const int row2 = wrap(r0 + (k - 1) * d);
+      float g[9][4];
+      lds_window_gather(lw1, par, top1, up, g);
+      m2 = m_mid1;
+      const float t2 = collide4(g, m2, a.omega, row2 == a.accel_row || row2 == a.accel_row_b, a.aw1, a.aw2, top2);
+      if (owner && k >= 4 && k <= n + 3) sum2 += t2;
+    }
+    lds_window_put(lw1, par, top1, up);
+    m_mid1 = m1;
+    if (PHASE == 3) {
+      lds_put_trail(theirs, 0, top1, !up);  // my first level-1 row: the partner's trail at its iteration 4
+      __syncthreads();
+    }
+    if (PHASE == 0 ? k >= 4 : PHASE == 5) {
+      const int row3 = wrap(r0 + (k - 2) * d);
+      float g[9][4];
+      lds_window_gather(lw2, par, top2, up, g);
+      m3 = m_mid2;
+      const float t3 = collide4(g, m3, a.omega, row3 == a.accel_row || row3 == a.accel_row_b, a.aw1, a.aw2, top3);
+      if (owner && k >= 5 && k <= n + 4) sum3 += t3;
+    }
+    if (PHASE == 5) {
+      // my first level-3 row goes through the trail slots of the partner's window 2 (parity 1), which its level-3
+      // gather of this iteration has just consumed, into the partner's register window
+      __syncthreads();
+      lds_put_trail(theirs + kWinSlots * 64, 1, top3, !up);
+      __syncthreads();
+      window_rotate(w3, top3, m3, up);
+      lds_get(lw2, 3 + 3, w3.trail[0]); lds_get(lw2, 4 + 3, w3.trail[1]); lds_get(lw2, 5 + 3, w3.trail[2]);
+      if (kW3Lds == 2) { lds_put(lw3, 0, w3.mid[0]); lds_put(lw3, 1, w3.mid[1]); }
+      m_mid3 = m3;
+    }
+    if (PHASE == 0 ? k >= 2 : PHASE >= 4) {
+      lds_window_put(lw2, par, top2, up);
+      m_mid2 = m2;
+    }
+    if (PHASE == 4) {
+      lds_put_trail(theirs + kWinSlots * 64, 1, top2, !up);  // my first level-2 row: the partner's trail at its iteration 5
+      __syncthreads();
+    }
+    if (PHASE == 0) {
+      if (k >= 6) {
+        const int y = r0 + (k - 3) * d;
+        float g[9][4], o[9][4];
+        if (kW3Lds == 2) { lds_get(lw3, 0, w3.mid[0]); lds_get(lw3, 1, w3.mid[1]); }
+        window_gather(w3, top3, up, g);
+        const float t4 = collide4(g, m_mid3, a.omega, (y == a.accel_row || y == a.accel_row_b) && a.accel_next, a.aw1, a.aw2, o);
+        if (owner) {
+          sum4 += t4;
+          float *dp = a.dst + (size_t)y * a.row_stride + xcol;
+#pragma unroll
+          for (int kk = 0; kk < 9; kk++) store4<NT>(dp + kk * ps, o[kk][0], o[kk][1], o[kk][2], o[kk][3]);
+        }
+      }
+      if (k >= 4) {
+        window_rotate(w3, top3, m3, up);
+        if (kW3Lds == 2) { lds_put(lw3, 0, w3.mid[0]); lds_put(lw3, 1, w3.mid[1]); }
+        m_mid3 = m3;
+      }
+    }
+  };
+  int kstart = 0;
+  if (paired) {
+    iter(3, 3);
+    iter(4, 4);
+    iter(5, 5);
+    kstart = 6;
+  }
+  for (int k = kstart; k <= n + 5; k++) iter(k, 0);
   sum1 = wave_sum(sum1);
   sum2 = wave_sum(sum2);
   sum3 = wave_sum(sum3);

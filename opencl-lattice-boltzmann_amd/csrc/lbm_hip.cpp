@@ -108,6 +108,8 @@ struct FuseGeom {
   int *chunk_start = nullptr;  // device array [nchunks+1]
   int nchunks = 0, nbands = 1, units_per_band = 0, units = 0;
   int skip = -1;               // chunk whose units do nothing (the interior, in an edge schedule)
+  bool single_round = false;   // all units of the launch are resident at once (equal chunks)
+  bool paired = false;         // launched with the chunk-pair kernel (d2q9_step3p / d2q9_step4p)
 };
 
 struct Slab {
@@ -175,6 +177,7 @@ struct lbm_ctx {
   int windows = -1;         // d2q9_step3 register windows: 0 = in registers (1 wave/SIMD), 1 = in LDS (2 waves/SIMD), -1 auto
   int load_bufs = 0;        // d2q9_step3 row-sets of loads in flight: 1, 2, 0 = auto
   int sched_waves = 0;      // waves per SIMD the d2q9_step3 schedule plans for: 1, 2, 0 = auto
+  int pair = -1;            // d2q9_step3p (chunk pairs share their start-up rows): 1 on, 0 off, -1 auto
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
   int chunk_min = 0;        // shortest chunk at the tapered end of a band (0 = auto)
@@ -221,15 +224,17 @@ void split_rows(int ny, int P, int idx, int *y0, int *rows) {
 bool windows_in_lds(const lbm_ctx *c) { return c->windows < 0 ? kStep3LdsDefault : c->windows != 0; }
 int step3_load_bufs(const lbm_ctx *c) { return c->load_bufs > 0 ? c->load_bufs : (windows_in_lds(c) ? 1 : 2); }
 
-// waves per SIMD the d2q9_step3 schedule plans for: two with the windows in LDS — except on grids of up to 800K cells,
-// where one round of 1024 longer units beats 1.5 waves per SIMD of shorter ones (tools/ab_small_mid.py, GLUPS planned
-// for 2 / 1: 1024x512 81 / 93, 768x768 90 / 102, 1280x512 97 / 100, 1024x768 112 / 112, 1024x1024 119 / 118)
+bool step3_can_pair(const lbm_ctx *c) { return windows_in_lds(c) && step3_load_bufs(c) == 1 && c->pair != 0; }
+
+// waves per SIMD the d2q9_step3 schedule plans for: two with the windows in LDS.  (The unpaired kernel did better with
+// one round of 1024 longer units on grids of up to 800K cells — 1024x512 81 / 93 GLUPS planned for 2 / 1, 768x768 90 /
+// 102; with chunk pairs, d2q9_step3p, two waves per SIMD win everywhere: 98 and 107, tools/ab_pair.py.)
 int step3_sched_waves(const lbm_ctx *c) {
   if (c->sched_waves > 0) return c->sched_waves;
   if (!windows_in_lds(c)) return 1;
+  if (step3_can_pair(c)) return 2;
   return (long)c->p.nx * c->rows_min <= 800L * 1024 ? 1 : 2;
 }
-
 int step4_sched_waves(const lbm_ctx *c) { return c->sched_waves > 0 ? c->sched_waves : 2; }
 
 bool fuse_possible(const lbm_ctx *c) {
@@ -281,13 +286,31 @@ int multistep_effective(const lbm_ctx *c) {
 // `cmax` rows and ends with ever shorter ones (guided self-scheduling), down to `cmin`.  (R full rounds of equal
 // chunks instead of the taper: within +-2 % on 8192x1024 ... 8192x8192, no consistent sign — not adopted.)
 int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g, int waves_per_simd = 2,
-                  int reserve = 0) {
+                  int reserve = 0, bool pairs = false) {
   const int rows = r1 - r0;
   g.nbands = (allow_bands && rows >= 8 * 4 * cmin) ? 8 : 1;
   // CUs x SIMDs x waves per SIMD the kernel's registers / LDS allow, minus the wave slots a concurrent launch needs
   // (slab mode: the edge launch, which must find its slots at once — see slab_geometry)
   const int waves_resident = std::max(256, 256 * 4 * waves_per_simd - reserve);
-  const double slots = std::max(1.0, (double)waves_resident / g.nbands / s.strips);  // concurrent chunks per band
+  // The chunk-pair kernels (d2q9_step3p / d2q9_step4p) hold the LDS of BOTH chunks of a pair until the longer one is
+  // done, so a one-round schedule needs an EVEN number of chunks per band that still fits the wave slots: 7.3 slots
+  // per band means 6 chunks with 8 bands (82 % of the slots) but 14 with 4 bands (96 %) — take the band count that
+  // keeps most waves busy, preferring more bands (neighbouring strips then share an XCD's L2).
+  g.single_round = false;
+  if (pairs && g.nbands == 8) {
+    int best_nb = 8;
+    double best = -1.0;
+    for (int nb = 8; nb >= 1; nb /= 2) {
+      const int fl = std::max(2, (int)std::floor((double)waves_resident / nb / s.strips) & ~1);
+      const int nrows = div_up(rows, nb);
+      if ((int)std::ceil((double)nrows / fl) > cmax) continue;  // not a one-round schedule with this band count
+      const double busy = (double)std::min(fl, nrows) * nb * (1.0 + 0.01 * nb);
+      if (busy > best) { best = busy; best_nb = nb; }
+    }
+    g.nbands = best_nb;
+  }
+  double slots = std::max(1.0, (double)waves_resident / g.nbands / s.strips);  // concurrent chunks per band
+  if (pairs) slots = std::max(2.0, (double)((int)std::floor(slots) & ~1));
   std::vector<int> starts;
   int chunks_per_band = 0;
   for (int b = 0; b < g.nbands; b++) {
@@ -301,6 +324,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     // 2560 units: 12.1; 4-row chunks = 1280 units: 11.6 — tools/ab_1024.py)
     const int one_round = (int)std::ceil(n / std::max(1.0, std::floor(slots)));
     const bool single_round = one_round <= cmax;
+    if (b == 0) g.single_round = single_round;
     while (rem > 0) {
       int sz = single_round ? std::max(2, one_round) : (int)std::ceil(rem / (2.0 * slots));
       if (!single_round) sz = std::max(cmin, std::min(cmax, sz));
@@ -310,7 +334,8 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     }
     // all bands need the same number of chunks (unit arithmetic in the kernel): band 0 is never
     // shorter than the others (split_rows); pad with empty chunks / merge surplus into the last one
-    if (b == 0) chunks_per_band = (int)sizes.size();
+    // (an even count for the chunk-pair kernels, which pair chunks 2p and 2p+1)
+    if (b == 0) chunks_per_band = pairs ? ((int)sizes.size() + 1) / 2 * 2 : (int)sizes.size();
     while ((int)sizes.size() < chunks_per_band) sizes.push_back(0);
     int extra = 0;
     while ((int)sizes.size() > chunks_per_band) { extra += sizes.back(); sizes.pop_back(); }
@@ -328,6 +353,25 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
   if (dev_alloc(&g.chunk_start, starts.size())) return LBM_ERR_HIP;
   HIP_TRY(hipMemcpy(g.chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
   return LBM_OK;
+}
+
+// Schedule for a kernel that has a chunk-pair form.  Pairs pay off where chunks are short, i.e. in one-round schedules
+// (tools/ab_pair4.py, unpaired / paired GLUPS: 1024x1024 117 / 143, 2048x1024 165 / 192, 2048x2048 211 / 223,
+// 4096x4096 268 / 273); with the long chunks of multi-round schedules the two waves of a workgroup only hold each
+// other's LDS (8192x8192 295 / 289).  c->pair: -1 = that rule, 1 = always, 0 = never.
+int fuse_schedule_pairs(const lbm_ctx *c, const Slab &s, int r0, int r1, int cmax, int cmin, FuseGeom &g, int waves_per_simd,
+                        int reserve, bool kernel_can_pair) {
+  g.paired = false;
+  // (not with row slabs: next to the edge launch's 20-KB workgroups and the RCCL kernel the 40-KB pairs of the interior
+  // launch no longer all fit at once — 8192x1024 ring of one: 168 GLUPS paired, 232 unpaired, tools/ab_ring_pair.py)
+  if (kernel_can_pair && c->pair != 0 && !(c->halo_mode && c->pair < 0)) {
+    if (int rc = fuse_schedule(s, r0, r1, cmax, cmin, true, g, waves_per_simd, 2 * reserve, true)) return rc;
+    if (g.single_round || c->pair > 0) {
+      g.paired = true;
+      return LBM_OK;
+    }
+  }
+  return fuse_schedule(s, r0, r1, cmax, cmin, true, g, waves_per_simd, reserve, false);
 }
 
 // All launch geometry of a slab (single-step workgroup counts, fused schedules, ring slot stride).
@@ -408,12 +452,13 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       tab.push_back(s.row0 + s.edge_rows);
       for (int y = 0; y < s.edge_rows; y += ec) tab.push_back(s.row0 + s.rows - s.edge_rows + y);
       tab.push_back(s.row0 + s.rows);
+      if (tab.size() % 2 == 0) tab.push_back(s.row0 + s.rows);  // an empty last chunk: even chunk count for d2q9_step3p
       if (set_dev(s)) return LBM_ERR_HIP;
       if (e.chunk_start) HIP_TRY(hipFree(e.chunk_start));
       e.chunk_start = nullptr;
       if (dev_alloc(&e.chunk_start, tab.size())) return LBM_ERR_HIP;
       HIP_TRY(hipMemcpy(e.chunk_start, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-      e.nchunks = 2 * n_edge_chunks + 1;  // the middle chunk [row0+edge, row0+rows-edge) is skipped by the kernel
+      e.nchunks = (int)tab.size() - 1;    // the middle chunk [row0+edge, row0+rows-edge) is skipped by the kernel
       e.skip = n_edge_chunks;
       e.nbands = 1;
       e.units_per_band = e.nchunks * s.strips;
@@ -424,10 +469,10 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
         // in one round of equal units starves the edge workgroups that were not dispatched first until other EDGE
         // workgroups retire (kernel trace, 8192x1024 slab, d2q9_step4: edge kernel 140 us instead of 50, and with
         // the exchange behind it the critical path of the launch set)
-        const int rsv = (e.nchunks - 1) * s.strips;  // the edge units that do work (those of the skipped chunk exit at once)
+        const int rsv = 2 * n_edge_chunks * s.strips;  // the edge units that do work (skipped and empty chunks exit at once)
         if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main, 2, rsv)) return rc;
-        if (int rc = fuse_schedule(s, i0, i1, c3max, c3min, true, s.f3_main, step3_sched_waves(c), rsv)) return rc;
-        if (int rc = fuse_schedule(s, i0, i1, c4max, c4min, true, s.f4_main, step4_sched_waves(c), rsv)) return rc;
+        if (int rc = fuse_schedule_pairs(c, s, i0, i1, c3max, c3min, s.f3_main, step3_sched_waves(c), rsv, step3_can_pair(c))) return rc;
+        if (int rc = fuse_schedule_pairs(c, s, i0, i1, c4max, c4min, s.f4_main, step4_sched_waves(c), rsv, windows_in_lds(c))) return rc;
       } else {
         s.f_main.units = s.f3_main.units = s.f4_main.units = 0;
       }
@@ -435,9 +480,9 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     } else {
       if (int rc = fuse_schedule(s, 0, s.rows, cmax, cmin, true, s.f_main)) return rc;
       s.nb_total = std::max(s.nb_total, s.f_main.units);
-      if (int rc = fuse_schedule(s, 0, s.rows, c3max, c3min, true, s.f3_main, step3_sched_waves(c))) return rc;
+      if (int rc = fuse_schedule_pairs(c, s, 0, s.rows, c3max, c3min, s.f3_main, step3_sched_waves(c), 0, step3_can_pair(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f3_main.units);
-      if (int rc = fuse_schedule(s, 0, s.rows, c4max, c4min, true, s.f4_main, step4_sched_waves(c))) return rc;
+      if (int rc = fuse_schedule_pairs(c, s, 0, s.rows, c4max, c4min, s.f4_main, step4_sched_waves(c), 0, windows_in_lds(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f4_main.units);
     }
   }
@@ -538,8 +583,20 @@ void launch_step3_v(int ntl, const Step2Args &a, float *partials3, int units, hi
   else hipLaunchKernelGGL((d2q9_step3<true, 0, WLDS, NBUF>), grid, block, 0, st, a, partials3);
 }
 
-void launch_step3(const lbm_ctx *c, const Step2Args &a, float *partials3, int units, hipStream_t st) {
+void launch_step3(const lbm_ctx *c, const Step2Args &a0, float *partials3, int units, hipStream_t st, bool paired = false) {
   const bool lds = windows_in_lds(c);
+  if (paired) {
+    // one workgroup of two waves per pair of chunks: a.units_per_band counts pairs x strips
+    Step2Args a = a0;
+    a.units_per_band = a0.units_per_band / 2;
+    const int ntl = c->nt_loads >= 0 ? c->nt_loads : 0;
+    const dim3 grid(units / 2), block(128);
+    if (ntl == 2) hipLaunchKernelGGL((d2q9_step3p<true, 2>), grid, block, 0, st, a, partials3);
+    else if (ntl == 1) hipLaunchKernelGGL((d2q9_step3p<true, 1>), grid, block, 0, st, a, partials3);
+    else hipLaunchKernelGGL((d2q9_step3p<true, 0>), grid, block, 0, st, a, partials3);
+    return;
+  }
+  const Step2Args &a = a0;
   // source loads: with two waves per SIMD (LDS windows) plain loads win at every size — 8192x8192 227.6 against 221.4
   // GLUPS with the hybrid scheme, 202.3 all non-temporal; 2048x2048 180.8 / 175.2 / 165.3; 1024x1024 117.9 / 116.4 /
   // 106.0 (tools/ab_mid4.py) — the rows a chunk shares with its neighbours and the strips' edge lines stay in L2;
@@ -552,8 +609,19 @@ void launch_step3(const lbm_ctx *c, const Step2Args &a, float *partials3, int un
   else launch_step3_v<false, 2>(ntl, a, partials3, units, st);
 }
 
-void launch_step4(const lbm_ctx *c, const Step2Args &a, float *partials3, float *partials4, int units, hipStream_t st) {
+void launch_step4(const lbm_ctx *c, const Step2Args &a0, float *partials3, float *partials4, int units, hipStream_t st,
+                  bool paired = false) {
   const int ntl = c->nt_loads >= 0 ? c->nt_loads : 0;
+  if (paired) {
+    Step2Args a = a0;
+    a.units_per_band = a0.units_per_band / 2;  // chunk pairs x strips
+    const dim3 grid(units / 2), block(128);
+    if (ntl == 2) hipLaunchKernelGGL((d2q9_step4p<true, 2>), grid, block, 0, st, a, partials3, partials4);
+    else if (ntl == 1) hipLaunchKernelGGL((d2q9_step4p<true, 1>), grid, block, 0, st, a, partials3, partials4);
+    else hipLaunchKernelGGL((d2q9_step4p<true, 0>), grid, block, 0, st, a, partials3, partials4);
+    return;
+  }
+  const Step2Args &a = a0;
   const dim3 grid(units), block(64);
   if (ntl == 2) hipLaunchKernelGGL((d2q9_step4<true, 2>), grid, block, 0, st, a, partials3, partials4);
   else if (ntl == 1) hipLaunchKernelGGL((d2q9_step4<true, 1>), grid, block, 0, st, a, partials3, partials4);
@@ -753,12 +821,12 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           a.partials1 = slot1;
           a.partials2 = slot2;
           float *slot3 = slot2 + s.nb_total;
-          launch_step4(c, a, slot3, slot3 + s.nb_total, s.f4_main.units, s.s_main);
+          launch_step4(c, a, slot3, slot3 + s.nb_total, s.f4_main.units, s.s_main, s.f4_main.paired);
         } else if (kind == KIND_FUSED3) {
           Step2Args a = base_args2(c, s, src, !last, s.f3_main);
           a.partials1 = slot1;
           a.partials2 = slot2;
-          launch_step3(c, a, slot2 + s.nb_total, s.f3_main.units, s.s_main);
+          launch_step3(c, a, slot2 + s.nb_total, s.f3_main.units, s.s_main, s.f3_main.paired);
         } else if (kind == KIND_FUSED2) {
           Step2Args a = base_args2(c, s, src, !last, s.f_main);
           a.partials1 = slot1;
@@ -808,7 +876,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           Step2Args m = base_args2(c, s, src, !last, s.f4_main);
           m.partials1 = slot1;
           m.partials2 = slot2;
-          launch_step4(c, m, slot3, slot4, s.f4_main.units, s.s_main);
+          launch_step4(c, m, slot3, slot4, s.f4_main.units, s.s_main, s.f4_main.paired);
           HIP_TRY(hipGetLastError());
         }
       } else if (kind == KIND_FUSED3) {
@@ -823,7 +891,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           Step2Args m = base_args2(c, s, src, !last, s.f3_main);
           m.partials1 = slot1;
           m.partials2 = slot2;
-          launch_step3(c, m, slot3, s.f3_main.units, s.s_main);
+          launch_step3(c, m, slot3, s.f3_main.units, s.s_main, s.f3_main.paired);
           HIP_TRY(hipGetLastError());
         }
       } else if (kind == KIND_FUSED2) {
@@ -1355,6 +1423,11 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     c->tile_shape = (int)value;
     return rebuild_geometry(c);
   }
+  if (!strcmp(key, "pair")) {
+    if (int rc = sync_all(c)) return rc;
+    c->pair = (int)value;
+    return rebuild_geometry(c);
+  }
   if (!strcmp(key, "windows") || !strcmp(key, "load_bufs") || !strcmp(key, "sched_waves")) {
     if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "%s out of range", key);
     if (int rc = sync_all(c)) return rc;
@@ -1392,6 +1465,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
+  else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;

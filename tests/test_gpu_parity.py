@@ -607,17 +607,18 @@ def test_odd_large_shapes_all_kernels_agree(lbm, nx, ny):
 @pytest.mark.parametrize("nx,ny,chunk", [(256, 8, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (2048, 16, 16), (260, 33, 4),
                                          (8192, 24, 8)])
 @pytest.mark.parametrize("nsteps", [3, 4, 5, 10])
-@pytest.mark.parametrize("windows,bufs", [(1, 1), (0, 2), (1, 2), (0, 1)])
-def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, windows, bufs):
+@pytest.mark.parametrize("windows,bufs,pair", [(1, 1, 1), (1, 1, 0), (0, 2, 0), (1, 2, 0), (0, 1, 0)])
+def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, windows, bufs, pair):
     """d2q9_step3 (three timesteps per launch; the two windows of intermediate rows in LDS — the default — or in
-    registers, one or two row-sets of loads in flight): bit-identical to single steps; step counts that are no
-    multiple of three finish with the two-step / single-step kernels"""
+    registers, one or two row-sets of loads in flight; d2q9_step3p = chunk pairs sharing their start-up rows):
+    bit-identical to single steps; step counts that are no multiple of three finish with the two-step / single-step
+    kernels"""
     rng = np.random.default_rng(3 * nx + ny + nsteps)
     ob, cells0 = random_case(rng, nx, ny)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     got, av = run_gpu(lbm, p, ob, cells0, nsteps, {"multistep": 0, "fuse": 3, "windows": windows, "load_bufs": bufs,
-                                                   "chunk_rows": chunk})
+                                                   "pair": pair, "chunk_rows": chunk})
     assert np.array_equal(got, single)
     assert max_rel(av, av_single) < 2e-6
 
@@ -625,17 +626,19 @@ def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, 
 @pytest.mark.parametrize("nx,ny,chunk", [(256, 8, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (2048, 16, 16), (260, 33, 4),
                                          (8192, 24, 8), (1024, 300, 128)])
 @pytest.mark.parametrize("nsteps", [4, 5, 6, 7, 13])
-def test_four_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps):
-    """d2q9_step4 (four timesteps per launch: two LDS windows + one register window): bit-identical to single steps;
+@pytest.mark.parametrize("pair", [1, 0])
+def test_four_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, pair):
+    """d2q9_step4 (four timesteps per launch: two LDS windows + one register window) and d2q9_step4p (chunk pairs that
+    hand each other their first row of every level instead of computing it twice): bit-identical to single steps;
     the steps left over after the last full launch go to the three-step / two-step / single-step kernels"""
     rng = np.random.default_rng(4 * nx + ny + nsteps)
     ob, cells0 = random_case(rng, nx, ny)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     with lbm.LBM(p, ob) as sim:
-        for k, v in {"multistep": 0, "fuse": 4, "chunk_rows": chunk}.items():
+        for k, v in {"multistep": 0, "fuse": 4, "pair": pair, "chunk_rows": chunk}.items():
             sim.set_option(k, v)
-        assert sim.get_option("fuse") == 4
+        assert sim.get_option("fuse") == 4 and sim.get_option("pair") == pair
         sim.upload(cells0)
         sim.run(nsteps)
         got, av = sim.download()
