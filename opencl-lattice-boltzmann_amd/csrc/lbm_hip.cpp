@@ -252,11 +252,11 @@ int fuse_level(const lbm_ctx *c) {
     // auto (same-box A/B, tools/ab_mid.py + tools/ab_fuse3.py, GLUPS two-step / three-step): the smallest grids go
     // to the LDS tile kernel (multistep_effective); 768x512 89 / 86 -> two steps per launch; 1024x512 82 / 93,
     // 768x768 89 / 102, 1024x768 106 / 112, 1024x1024 114 / 119, 1536x1024 127 / 147 -> three steps per launch
-    // ... and four steps per launch from 2M cells up (tools/ab_step4d.py, three / four steps: 1024x1024 120 / 114,
-    // 1536x1024 151 / 147, 2048x1024 156 / 164, 2048x2048 188 / 216, 4096x2048 205 / 252, 4096x4096 219 / 275,
-    // 8192x1024 206 / 246, 8192x8192 235 / 298)
+    // ... and four steps per launch from 1.25M cells up (tools/ab_pair4.py, three / four steps, chunk pairs where the
+    // launch is one round: 1024x768 129 / 128, 1024x1024 143 / 136, 1536x1024 162 / 175, 2048x1024 170 / 192,
+    // 2048x2048 183 / 223, 4096x4096 217 / 273, 8192x8192 230 / 295)
     const long cells = (long)c->p.nx * c->rows_min;
-    lvl = cells >= (2L << 20) ? 4 : (cells > 450L * 1024 ? 3 : 2);
+    lvl = cells >= 1280L * 1024 ? 4 : (cells > 450L * 1024 ? 3 : 2);
   }
   if (lvl == 4 && ((c->halo_mode && c->halo_depth < 4) || !windows_in_lds(c))) lvl = 3;  // needs 4 halo rows, LDS windows
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
