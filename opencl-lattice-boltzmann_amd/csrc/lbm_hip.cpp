@@ -870,7 +870,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
         e.skip_chunk = s.f_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
         e.partials1 = slot1 + s.f4_main.units;
         e.partials2 = slot2 + s.f4_main.units;
-        launch_step4(c, e, slot3 + s.f4_main.units, slot4 + s.f4_main.units, s.f_edge.units, s.s_edge);
+        launch_step4(c, e, slot3 + s.f4_main.units, slot4 + s.f4_main.units, s.f_edge.units, s.s_edge, s.f4_main.paired);
         HIP_TRY(hipGetLastError());
         if (s.f4_main.units > 0) {
           Step2Args m = base_args2(c, s, src, !last, s.f4_main);
@@ -885,7 +885,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
         e.skip_chunk = s.f_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
         e.partials1 = slot1 + s.f3_main.units;
         e.partials2 = slot2 + s.f3_main.units;
-        launch_step3(c, e, slot3 + s.f3_main.units, s.f_edge.units, s.s_edge);
+        launch_step3(c, e, slot3 + s.f3_main.units, s.f_edge.units, s.s_edge, s.f3_main.paired);
         HIP_TRY(hipGetLastError());
         if (s.f3_main.units > 0) {
           Step2Args m = base_args2(c, s, src, !last, s.f3_main);
