@@ -164,9 +164,11 @@ def main():
     # one GPU per rank; if the launcher narrowed the visible devices per rank, index within what is visible
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    # LBM_BENCH_RANK_MODE=1 (with LBM_FORCE_HALO=1) drives the one-process-per-GPU code path with a single rank: the
-    # rank is its own ring neighbour, so torch.distributed + the library's RCCL communicator run on a one-GPU box
+    # LBM_BENCH_RANK_MODE=1 drives the one-process-per-GPU code path with a single rank: the rank is its own ring
+    # neighbour (default "force_halo"), so torch.distributed + the library's RCCL communicator run on a one-GPU box
     rank_mode = world > 1 or os.environ.get("LBM_BENCH_RANK_MODE") == "1"
+    if rank_mode and world == 1:
+        lbm_amd.set_default("force_halo", 1)
     dist = init_dist("nccl", rank, world, torch.device("cuda", local_rank)) if rank_mode else None
 
     nx = args.nx

@@ -33,7 +33,7 @@ extern "C" {
 #define LBM_ERR_ARG 1    /* bad argument */
 #define LBM_ERR_HIP 2    /* HIP runtime error (message has the hipError string) */
 #define LBM_ERR_STATE 3  /* call not valid in the context's current state */
-#define LBM_ERR_COMM 4   /* RCCL error */
+#define LBM_ERR_COMM 4   /* halo transport error (RCCL, peer mapping, a neighbour that never arrived) */
 
 /* Run constants: the reference's t_param (d2q9-bgk.c:81-92), same fields. */
 typedef struct lbm_params {
@@ -56,8 +56,10 @@ typedef struct lbm_ctx lbm_ctx; /* opaque; replaces t_ocl (d2q9-bgk.c:97-119) */
  *   obstacles  borrowed for the duration of the call.
  *   ndev       number of row slabs; the grid is row-partitioned over dev_ids[0..ndev).  ndev <= 1
  *              with dev_ids == NULL uses the current HIP device.  A device may be listed more than
- *              once (several slabs on one GPU): halos then move by device-to-device copies instead
- *              of RCCL.  Every slab needs at least 4 rows.
+ *              once (several slabs on one GPU).  Every slab needs at least 4 rows.  Halo rows move by
+ *              the PEER transport (a kernel stores them straight into the neighbour slab's halo rows,
+ *              peer access between distinct devices) unless lbm_set_default("transport") asks for
+ *              RCCL send/recv (distinct devices only) or device-to-device copies.
  */
 int lbm_create(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles, int ndev, const int *dev_ids);
 
@@ -68,11 +70,40 @@ int lbm_create(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles
  * lbm_comm_id_size()-byte blob produced by lbm_comm_get_id() on one rank and distributed by the
  * caller (e.g. torch.distributed broadcast).  params/obstacles describe the GLOBAL grid.
  * No counterpart in the reference (single device); mandated by the multi-GPU configs.
+ * comm_id == NULL creates the rank without RCCL communicator: it must then be connected with
+ * lbm_connect_peers before the first lbm_run, and lbm_download returns the velocity sums over THIS rank's
+ * rows only (times free_cells_inv) — the caller adds the ranks' records.
  */
 int lbm_create_rank(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles,
                     int rank, int nranks, int device, const void *comm_id);
 size_t lbm_comm_id_size(void);
 int lbm_comm_get_id(void *comm_id_out);
+
+/*
+ * PEER halo transport between ranks (the low-latency alternative to RCCL send/recv for the halo rows; the
+ * all-reduce stays with RCCL).  Each rank describes its two grids and its flag words in an
+ * lbm_peer_info_size()-byte blob (HIP IPC handles + the raw pointers for neighbours inside the same process);
+ * the caller distributes the blobs (e.g. torch.distributed all_gather) and hands every rank the blobs of its ring
+ * neighbours (rank-1) mod nranks and (rank+1) mod nranks.  From then on a launch set's edge rows are stored
+ * straight into the neighbours' halo rows by a push kernel (xGMI peer writes) which then raises a sequence
+ * number in the neighbour's flag word; the consumer waits for it with a bounded spin (30 s; reported by lbm_sync
+ * as LBM_ERR_COMM) or hipStreamWaitValue32 (option "halo_sync").  lbm_connect_peers is a collective decision:
+ * every rank of the ring must call it (or none); lbm_set_option("transport", 1 | 3) switches a connected context
+ * that also has a communicator between RCCL send/recv and peer stores.
+ */
+size_t lbm_peer_info_size(void);
+int lbm_peer_info(lbm_ctx *ctx, void *info_out);
+int lbm_connect_peers(lbm_ctx *ctx, const void *south_info, const void *north_info);
+
+/*
+ * Process-wide defaults for contexts created afterwards (validated; replace the environment hooks of round 1):
+ *   "force_halo"  0 | 1   a single slab also carries halo rows and exchanges them with itself (a ring of one): the
+ *                         whole multi-GPU machinery of a rank on one GPU (tests, tools/scaling_projection.py)
+ *   "halo_depth"  0 = by slab size (8 small slabs / 4 from 2M cells / 3 / 2 thin slabs), else 2..8
+ *   "transport"   0 = auto, 1 = RCCL send/recv, 2 = device-to-device copies, 3 = peer stores
+ *   "lanes_out"   0 = auto (60), else 4..62: output lanes per 64-lane strip of the window kernels
+ */
+int lbm_set_default(const char *key, long value);
 
 /*
  * Host -> device copy of the initial state.  Replaces clEnqueueWriteBuffer(cells)
@@ -93,6 +124,20 @@ int lbm_run(lbm_ctx *ctx, int nsteps);
 /* lbm_run + device-side timing: *ms = elapsed time of the nsteps step loop measured with HIP
  * events recorded on the stream the kernels run on (max over slabs).  Synchronises. */
 int lbm_run_timed(lbm_ctx *ctx, int nsteps, double *ms);
+
+/*
+ * lbm_run with timing events around every launch of the context's first slab (at most 64 launch sets are
+ * recorded; run few steps).  Synchronises.  stats[8] (microseconds are means over the recorded launch sets):
+ *   [0] launch sets recorded   [1] timesteps per launch set (mean)
+ *   [2] edge launch us         [3] halo exchange us (from the end of the edge launch to the end of the push
+ *                                  kernel / RCCL send+recv on the edge stream; the last set of a run has none)
+ *   [4] interior launch us (the only launch of a context without halo rows)
+ *   [5] launch-set period us (start of an interior launch to the start of the next)
+ *   [6] start of the interior launch after the start of the edge launch, us   [7] transport in use
+ * Diagnostic only (the events cost a few microseconds per set): bench.py --gpus N prints it per rank so that a
+ * multi-GPU record explains where a launch set's time went.
+ */
+int lbm_run_profiled(lbm_ctx *ctx, int nsteps, double *stats);
 
 /* Wait for all queued work.  Replaces clFinish (d2q9-bgk.c:239). */
 int lbm_sync(lbm_ctx *ctx);
@@ -146,8 +191,10 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "nt_loads"     source loads of the multi-step kernels: 0 = plain, 1 = non-temporal, 2 = non-temporal except
  *                  for the rows shared with the neighbouring chunk, -1 = auto (2 for the two-step kernel, 0 for
  *                  the three-step kernel with its windows in LDS)
- * Read-only through lbm_get_option: "transport" (1 = RCCL send/recv, 2 = device-to-device copies; chosen at
- * creation, environment LBM_TRANSPORT=rccl|copy overrides for single-process contexts), "nslabs", "fuse_units".
+ *   "transport"    halo transport of a context that carries halo rows: 1 = RCCL send/recv (needs a communicator),
+ *                  3 = peer stores (needs connected peers); read-only values 2 = device-to-device copies, 0 = none yet
+ *   "halo_sync"    peer transport, consumer side: 0 = wait kernel with a bounded spin (default), 1 = hipStreamWaitValue32
+ * Read-only through lbm_get_option: "nslabs", "fuse_units", "halo_depth".
  */
 int lbm_set_option(lbm_ctx *ctx, const char *key, long value);
 int lbm_get_option(const lbm_ctx *ctx, const char *key, long *value);

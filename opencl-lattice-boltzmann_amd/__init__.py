@@ -24,8 +24,11 @@ ABI_SYMBOLS = [
     "lbm_create", "lbm_create_rank", "lbm_comm_id_size", "lbm_comm_get_id", "lbm_upload", "lbm_run",
     "lbm_run_timed", "lbm_sync", "lbm_download", "lbm_steps_done", "lbm_row_range", "lbm_final_state",
     "lbm_reynolds", "lbm_set_option", "lbm_get_option", "lbm_copy_bandwidth", "lbm_destroy",
-    "lbm_last_error", "lbm_version",
+    "lbm_last_error", "lbm_version", "lbm_set_default", "lbm_peer_info_size", "lbm_peer_info", "lbm_connect_peers",
+    "lbm_run_profiled",
 ]
+
+TRANSPORTS = {"auto": 0, "rccl": 1, "copy": 2, "peer": 3}
 
 
 class LBMError(RuntimeError):
@@ -65,6 +68,7 @@ def load_library():
     L.lbm_upload.argtypes = [vp, vp]
     L.lbm_run.argtypes = [vp, ci]
     L.lbm_run_timed.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
+    L.lbm_run_profiled.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
     L.lbm_sync.argtypes = [vp]
     L.lbm_download.argtypes = [vp, vp, vp]
     L.lbm_steps_done.argtypes = [vp]
@@ -74,6 +78,10 @@ def load_library():
     L.lbm_set_option.argtypes = [vp, cp, ctypes.c_long]
     L.lbm_get_option.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_long)]
     L.lbm_copy_bandwidth.argtypes = [ctypes.c_size_t, ci, ctypes.POINTER(ctypes.c_double)]
+    L.lbm_set_default.argtypes = [cp, ctypes.c_long]
+    L.lbm_peer_info_size.restype = ctypes.c_size_t
+    L.lbm_peer_info.argtypes = [vp, vp]
+    L.lbm_connect_peers.argtypes = [vp, vp, vp]
     L.lbm_destroy.argtypes = [vp]
     L.lbm_destroy.restype = None
     L.lbm_last_error.restype = cp
@@ -155,6 +163,14 @@ def copy_bandwidth_gbps(nbytes=1 << 30, iters=20):
     return g.value
 
 
+def set_default(key, value):
+    """Process-wide default for contexts created afterwards (lbm_set_default): force_halo, halo_depth, transport
+    (number or one of TRANSPORTS), lanes_out."""
+    if key == "transport" and isinstance(value, str):
+        value = TRANSPORTS[value]
+    _check(load_library().lbm_set_default(key.encode(), int(value)), "lbm_set_default(%s)" % key)
+
+
 def comm_id():
     """RCCL unique id blob for lbm_create_rank (produce on one rank, broadcast to the others)."""
     L = load_library()
@@ -204,6 +220,14 @@ class LBM:
         _check(self.lib.lbm_run_timed(self.ctx, nsteps, ctypes.byref(ms)), "lbm_run_timed")
         return ms.value
 
+    def run_profiled(self, nsteps):
+        """Runs nsteps with timing events around every launch of the first slab; dict of mean microseconds."""
+        st = (ctypes.c_double * 8)()
+        _check(self.lib.lbm_run_profiled(self.ctx, nsteps, st), "lbm_run_profiled")
+        return {"sets": int(st[0]), "steps_per_set": st[1], "edge_us": st[2], "exchange_us": st[3], "interior_us": st[4],
+                "set_period_us": st[5], "interior_start_lag_us": st[6],
+                "transport": {0: "none", 1: "rccl", 2: "copy", 3: "peer"}.get(int(st[7]), "?")}
+
     def sync(self):
         _check(self.lib.lbm_sync(self.ctx), "lbm_sync")
 
@@ -234,6 +258,18 @@ class LBM:
         r = ctypes.c_float()
         _check(self.lib.lbm_reynolds(self.ctx, ctypes.byref(r)), "lbm_reynolds")
         return r.value
+
+    def peer_info(self):
+        """This rank's peer descriptor (bytes) for lbm_connect_peers on its ring neighbours."""
+        buf = ctypes.create_string_buffer(self.lib.lbm_peer_info_size())
+        _check(self.lib.lbm_peer_info(self.ctx, buf), "lbm_peer_info")
+        return buf.raw
+
+    def connect_peers(self, south_info, north_info):
+        """Descriptors of ranks (rank-1) and (rank+1) mod nranks: switches the halo transport to peer stores."""
+        so = ctypes.create_string_buffer(south_info, len(south_info))
+        no = ctypes.create_string_buffer(north_info, len(north_info))
+        _check(self.lib.lbm_connect_peers(self.ctx, so, no), "lbm_connect_peers")
 
     def set_option(self, key, value):
         _check(self.lib.lbm_set_option(self.ctx, key.encode(), int(value)), "lbm_set_option(%s)" % key)

@@ -1234,6 +1234,81 @@ __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *
   }
 }
 
+// ---- peer-halo transport: push kernel + flag words ------------------------------------------------
+// A slab's edge rows go straight into the ring neighbours' halo rows (peer-mapped memory: the same process, another
+// device with peer access, or another process through HIP IPC), followed by a sequence number in the neighbour's
+// flag word.  Protocol (csrc/lbm_hip.cpp, exchange_halos): the consumer waits for flag >= seq before the launch that
+// reads the halo rows; that the producer may overwrite them again follows from the data dependencies of the ring
+// (its next push comes after its next edge launch, which waited for this consumer's previous push, which came
+// after the consumer's last reader of those rows).
+struct PushArgs {
+  const float *src_lo, *src_hi;   // this slab's bottom / top edge rows (halo_depth rows each, contiguous)
+  float *dst_lo, *dst_hi;         // the south neighbour's top halo rows / the north neighbour's bottom halo rows
+  unsigned long long n4;          // float4 per block
+  uint32_t *flag_lo, *flag_hi;    // the neighbours' flag words for pushes arriving from this side
+  uint32_t seq;                   // sequence number of this exchange
+  unsigned *ticket;               // workgroups done (reset by the last one)
+};
+
+__device__ __forceinline__ void flag_store_system(uint32_t *flag, uint32_t v) {
+  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint32_t flag_load_system(const uint32_t *flag) {
+  return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// 16-byte WRITE-THROUGH store (sc0 sc1: system scope, nothing stays dirty in this XCD's L2).  The pushed halo rows
+// are made visible by these stores themselves plus each storing wave's s_waitcnt vmcnt(0) — not by release fences:
+// a fence writes back (and, as __threadfence_system, invalidates) the whole L2 of the XCD, which the interior launch
+// running beside the push is busy filling (first version, one fence per thread: 8192x1024 slab 44.1 instead of 38.1
+// us/step, gpurun_out r02/ab_ring1.txt).
+__device__ __forceinline__ void store4_through(float *p, v4f v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The last workgroup of `expected` to arrive publishes the sequence number.  Precondition: every wave of the calling
+// workgroup has drained its write-through stores (drain_stores) before the barrier in here.
+__device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned expected, uint32_t *flag_a, uint32_t *flag_b, uint32_t seq) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == expected - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next user starts after this kernel has ended
+      if (flag_a) flag_store_system(flag_a, seq);
+      if (flag_b) flag_store_system(flag_b, seq);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void halo_push(const PushArgs a) {
+  const unsigned half = gridDim.x >> 1;  // first half of the workgroups: bottom rows, second half: top rows
+  const bool hi = blockIdx.x >= half;
+  const v4f *src = reinterpret_cast<const v4f *>(hi ? a.src_hi : a.src_lo);
+  float *dst = hi ? a.dst_hi : a.dst_lo;
+  const unsigned b = hi ? blockIdx.x - half : blockIdx.x;
+  for (size_t i = (size_t)b * kBlock + threadIdx.x; i < a.n4; i += (size_t)half * kBlock) store4_through(dst + 4 * i, src[i]);
+  drain_stores();
+  publish_when_last(a.ticket, gridDim.x, a.flag_lo, a.flag_hi, a.seq);
+}
+
+// Consumer side: one wave, lanes 0 and 1 poll the two flag words until both have reached `seq`.  The spin is
+// BOUNDED (timeout in 100-MHz ticks of s_memrealtime): a neighbour that never arrives sets the error word, which
+// lbm_sync reports, instead of hanging the GPU.  The launch that follows starts with the usual kernel-start acquire.
+__global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+  if (threadIdx.x < 2) {
+    const uint32_t *f = flags + threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(flag_load_system(f) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
+        atomicOr(err, 1u);
+        break;
+      }
+    }
+  }
+}
+
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------
 // Grids of a few hundred cells a side are bound by launch latency, not bandwidth (one step of 128x128 is
 // ~2 us of work behind ~3.4 us of launch cost).  This kernel advances T <= kMultiMaxT steps per launch: a
@@ -1258,11 +1333,20 @@ struct MultiArgs {
   int ext_rows;             // rows stored (owned + halo rows below and above)
   int row_off;              // stored row of owned row 0; 0 = no halo rows: y wraps periodically inside the kernel
   int tiles_x;
-  int ty_begin, ty_split, ty_begin2;  // tile row of workgroup-row t: t < ty_split ? ty_begin + t : ty_begin2 + (t - ty_split)
+  int ty_begin, ty_split, ty_begin2;  // tile row of workgroup-row t: t < ty_split ? ty_begin + t : ty_begin2 + (t - ty_split) ...
+  int ty_split2, ty_begin3;           // ... and ty_begin3 + (t - ty_split2) from t = ty_split2 on (0 = no third range)
   int T;                    // steps in this launch (<= row_off when there are halo rows)
   int gy_off, ny_global;    // stored row r holds global row (gy_off + r) mod ny_global; accelerate_flow acts on ny_global-2
   int accel_next;           // apply the following step's accelerate_flow to the final state
   float omega, aw1, aw2;
+  // peer-halo transport, fused ("compact" launch sets of small slabs): the first edge_blocks workgroups hold the
+  // push_rows bottom and top owned rows; they store those rows a second time, write-through, into the ring neighbours'
+  // halo rows, and the last of them to finish raises the neighbours' flag words to seq.  push_rows == 0: off.
+  float *push_lo, *push_hi;     // the south neighbour's top halo rows / the north neighbour's bottom halo rows (plane 0, row 0)
+  uint32_t *flag_lo, *flag_hi;
+  unsigned *ticket;
+  uint32_t seq;
+  int push_rows, edge_blocks;
 };
 
 template <int kMultiTX, int kMultiTY>
@@ -1275,7 +1359,8 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
   const int T = a.T;
   const int RX = kMultiTX + 2 * T, RY = kMultiTY + 2 * T;
   const int trow = blockIdx.x / a.tiles_x, tile_x = blockIdx.x - trow * a.tiles_x;
-  const int tile_y = trow < a.ty_split ? a.ty_begin + trow : a.ty_begin2 + (trow - a.ty_split);
+  const int tile_y = trow < a.ty_split ? a.ty_begin + trow
+                     : ((a.ty_split2 > 0 && trow >= a.ty_split2) ? a.ty_begin3 + (trow - a.ty_split2) : a.ty_begin2 + (trow - a.ty_split));
   const int gx0 = tile_x * kMultiTX - T, oy0 = tile_y * kMultiTY - T;  // region cell (0,0): column, owned-row index
   const bool periodic = (a.row_off == 0);
   const size_t ps = a.plane_stride;
@@ -1366,6 +1451,28 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
     float t = wsum[tid][0];
     for (int i = 1; i < kMultiThreads / 64; i++) t += wsum[tid][i];
     a.partials[(size_t)tid * a.partials_stride + blockIdx.x] = t;
+  }
+  // fused push (see MultiArgs): the edge tiles' share of the rows the ring neighbours need, 16 bytes per lane straight
+  // from the LDS copy of the final state; a quad that hangs over the end of a row spills into the row padding
+  // (plane_stride is a multiple of 64 floats >= nx: never read)
+  if (a.push_rows > 0 && (int)blockIdx.x < a.edge_blocks) {
+    const int fin = T & 1;
+    constexpr int Q = kMultiTX / 4;
+    const int top0 = a.rows - a.push_rows;  // first owned row that goes north
+    for (int i = tid; i < 9 * kMultiTY * Q; i += kMultiThreads) {
+      const int k = i / (kMultiTY * Q), r = i - k * (kMultiTY * Q);
+      const int oy = r / Q, q = r - oy * Q;
+      const int orow = tile_y * kMultiTY + oy, gx = tile_x * kMultiTX + 4 * q;
+      if (orow >= a.rows || gx >= a.nx) continue;
+      const bool lo = orow < a.push_rows, hi = orow >= top0;
+      if (!lo && !hi) continue;
+      const float *src = &lds[fin][k][(oy + T) * kMultiRX + 4 * q + T];
+      v4f v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+      if (lo) store4_through(a.push_lo + (size_t)orow * a.row_stride + k * ps + gx, v);
+      if (hi) store4_through(a.push_hi + (size_t)(orow - top0) * a.row_stride + k * ps + gx, v);
+    }
+    drain_stores();
+    publish_when_last(a.ticket, (unsigned)a.edge_blocks, a.flag_lo, a.flag_hi, a.seq);
   }
 }
 

@@ -7,18 +7,22 @@
 //
 // Structure: a context owns one or more row SLABS.  A slab is a contiguous range of grid rows on
 // one GPU with its own pair of grids, mask, streams and reduction buffers.  With one slab the y
-// wrap-around is resolved inside the kernels.  With several slabs every slab stores two HALO rows
-// below and above its own rows inside the same row-interleaved arrays; after each launch set (two
-// timesteps with the fused kernel, one otherwise) a slab sends its two bottom and two top rows —
-// each pair one contiguous block — to its ring neighbours' halo rows (RCCL send/recv over xGMI, or
-// device-to-device copies when slabs share a process and RCCL cannot be used).  The chunks next to
-// the slab edges are computed first on an edge stream, so the exchange overlaps the interior work
-// on the main stream; events join the two streams once per launch set.
+// wrap-around is resolved inside the kernels.  With several slabs every slab stores H HALO rows (H = 2, 3,
+// 4 or 8: as many as a launch set advances timesteps) below and above its own rows inside the same
+// row-interleaved arrays; after each launch set a slab's H bottom and H top rows — each one contiguous
+// block — go to its ring neighbours' halo rows.  Three transports: PEER (default where it can be set up)
+// = a push kernel stores the rows straight into the neighbour's memory (same process, peer device, or
+// another process through HIP IPC) and raises a sequence number in the neighbour's flag word; RCCL =
+// grouped ncclSend/ncclRecv over xGMI; COPY = device-to-device hipMemcpy between slabs of one process.
+// The chunks next to the slab edges are computed first on an edge stream, so the exchange overlaps the
+// interior work on the main stream; events join the two streams once per launch set.
 #include "../../include/lbm.h"
 #include "d2q9_kernels.h"
+#include "halo_exchange.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -101,7 +105,38 @@ int load_rccl() {
 
 constexpr bool kStep3LdsDefault = true;   // d2q9_step3 windows in LDS unless option "windows" says otherwise
 constexpr int kRingMax = 256;  // most steps of per-workgroup partial sums buffered between reductions
-enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2 };
+constexpr int kProfSets = 64, kProfEvents = 5;  // lbm_run_profiled: {edge start, edge end, exchange end, interior start, interior end}
+enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2, TRANSPORT_PEER = 3 };
+
+// Process-wide defaults for contexts created afterwards (lbm_set_default): what used to be environment hooks.
+struct Defaults {
+  int force_halo = 0;               // 1: even a single slab carries halo rows and exchanges them with itself (ring of one)
+  int halo_depth = 0;               // 0 = by slab size, else 2..8
+  int transport = TRANSPORT_AUTO;   // halo transport of contexts that may choose
+  int lanes_out = 0;                // output lanes per strip of the window kernels: 0 = auto (60), else 4..62
+};
+Defaults g_defaults;
+
+// one ring neighbour as seen from a slab: its two grids and its flag words, mapped into this process
+struct PeerLink {
+  float *cells[2] = {nullptr, nullptr};
+  uint32_t *flags = nullptr;
+  int rows = 0;         // rows the neighbour owns (its top halo starts behind them)
+  bool ipc = false;     // opened with hipIpcOpenMemHandle: closed in free_slab
+  bool connected = false;
+};
+
+// what lbm_peer_info() hands to the caller for distribution to the ring neighbours
+struct PeerInfoBlob {
+  uint64_t magic;
+  int32_t pid, device;
+  int32_t rows, row0;
+  uint64_t row_stride;
+  uint64_t cells_ptr[2], flags_ptr;   // valid inside process `pid`
+  hipIpcMemHandle_t cells[2], flags;  // for everybody else
+};
+constexpr uint64_t kPeerMagic = 0x4c424d5045455231ull;  // "LBMPEER1"
+constexpr unsigned long long kHaloWaitTicks = 30ull * 100000000ull;  // 30 s of s_memrealtime (100 MHz)
 
 // unit schedule of one d2q9_step2 launch (see fuse_schedule)
 struct FuseGeom {
@@ -142,6 +177,11 @@ struct Slab {
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // timing of lbm_run_timed
   hipEvent_t ev_aux = nullptr;                  // cross-stream ordering inside a run
   ncclComm_t comm = nullptr;
+  // peer-halo transport: [0] exchanges completed by the south neighbour (its pushes into my bottom halo rows),
+  // [1] by the north neighbour, [2] error bits of halo_wait, [3] ticket of halo_push
+  uint32_t *halo_flags = nullptr;
+  PeerLink south, north;
+  double *av_tmp = nullptr;   // all-reduce target of the velocity record (rank mode), allocated on first use
   // output-stage scratch
   float *fin_partials = nullptr;
   int fin_blocks = 0;
@@ -167,6 +207,14 @@ struct lbm_ctx {
   int ring_fill = 0;        // buffered steps not yet reduced
   int ring = kRingMax;      // slots in the partial-sum ring (smaller for grids with many workgroups)
   int transport_eff = TRANSPORT_COPY;
+  uint32_t halo_seq = 0;    // exchanges issued so far (PEER transport: the value the neighbours' flags reach)
+  int halo_sync = 0;        // PEER transport, consumer side: 0 = halo_wait kernel (bounded spin), 1 = hipStreamWaitValue32
+  int compact = -1;         // PEER transport + d2q9_multi: one launch per launch set on ONE stream, the edge tiles push the
+                            // halo rows themselves (-1 auto = on, 0 off = edge stream / interior stream / push kernel)
+  bool failed = false;      // a run ended in an error after launches had begun: only lbm_destroy is valid
+  // lbm_run_profiled: timing events of the first local slab, kProfEvents per launch set, for up to kProfSets sets
+  std::vector<hipEvent_t> prof_ev;
+  int prof_sets = -1;       // -1: not profiling; else launch sets recorded so far in this run
   // options
   int variant = 0;
   int grid_blocks = 0;
@@ -412,8 +460,8 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     // tools/ab_lanes.py) although 60-lane strips leave more lanes idle
     s.strips = div_up(q4, 60);
     s.lanes_out = std::min(60, (div_up(q4, s.strips) + 3) / 4 * 4);
-    if (const char *lo = getenv("LBM_LANES_OUT")) {  // tuning: output lanes per strip (<= 62)
-      s.lanes_out = std::max(1, std::min(62, atoi(lo)));
+    if (g_defaults.lanes_out > 0) {  // lbm_set_default("lanes_out"): output lanes per strip (validated 4..62)
+      s.lanes_out = g_defaults.lanes_out;
       s.strips = div_up(q4, s.lanes_out);
     }
     // measured optimum (profiles/r01_fused_sweep.txt): short chunks — the rows concurrently in flight on an
@@ -441,11 +489,10 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       // wave's serial sweep and, with the exchange, the critical path of a launch set, profiles/r01_overlap_trace.txt)
       FuseGeom &e = s.f_edge;
       // edge schedule: chunk table {bottom edge rows, interior, top edge rows}; the launch skips the interior chunk.
-      // One chunk per edge by default.  Splitting an edge into single-row chunks (LBM_EDGE_CHUNK=1) shortens the edge
+      // One chunk per edge.  Splitting an edge into single-row chunks (a round-1 experiment) shortens the edge
       // kernel of d2q9_step3 from 47 to 32 us (5 instead of 7 iterations per wave) but did not shorten the launch set:
       // 8192x1024 ring of one 45.5 -> 47.0 us/step, 4096x512 18.3 -> 17.0, 2048x256 9.1 -> 9.3 (tools/ab_edge.sh)
-      int ec = s.edge_rows;
-      if (const char *v = getenv("LBM_EDGE_CHUNK")) ec = std::max(1, atoi(v));  // tuning: rows per edge chunk
+      const int ec = s.edge_rows;
       std::vector<int> tab;
       for (int y = 0; y < s.edge_rows; y += ec) tab.push_back(s.row0 + y);
       const int n_edge_chunks = (int)tab.size();
@@ -673,22 +720,83 @@ void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t s
   else hipLaunchKernelGGL((d2q9_step2<false>), dim3(units), dim3(64), 0, st, a);
 }
 
+// RCCL behind the transport concept of halo_exchange.h
+struct RcclTransport {
+  int group_start() { return (int)g_rccl.GroupStart(); }
+  int group_end() { return (int)g_rccl.GroupEnd(); }
+  int send(const void *p, size_t n, int peer, void *comm, void *stream) {
+    return (int)g_rccl.Send(p, n, ncclFloat, peer, (ncclComm_t)comm, (hipStream_t)stream);
+  }
+  int recv(void *p, size_t n, int peer, void *comm, void *stream) {
+    return (int)g_rccl.Recv(p, n, ncclFloat, peer, (ncclComm_t)comm, (hipStream_t)stream);
+  }
+};
+
+// PEER transport, consumer side: the launch that follows on `st` reads halo rows that exchange number `seq` fills
+int wait_halos(lbm_ctx *c, Slab &s, hipStream_t st, uint32_t seq) {
+  if (c->halo_sync == 1) {
+    HIP_TRY(hipStreamWaitValue32(st, s.halo_flags, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    HIP_TRY(hipStreamWaitValue32(st, s.halo_flags + 1, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  } else {
+    hipLaunchKernelGGL(halo_wait, dim3(1), dim3(64), 0, st, s.halo_flags, seq, s.halo_flags + 2, kHaloWaitTicks);
+    HIP_TRY(hipGetLastError());
+  }
+  return LBM_OK;
+}
+
+bool compact_sets(const lbm_ctx *c) {
+  return c->halo_mode && c->transport_eff == TRANSPORT_PEER && c->compact != 0 && multistep_effective(c) > 0;
+}
+
 // Slab mode: move the `halo_depth` bottom and top owned rows of grid `buf` into the ring neighbours' halo
 // rows of their grid `buf`.  Each group of rows is one contiguous block of halo_depth*row_stride floats.
-int exchange_halos(lbm_ctx *c, int buf, int evq) {
+int exchange_halos(lbm_ctx *c, int buf, int evq, bool on_main = false) {
   const int P = c->nslabs_global;
-  if (c->transport_eff == TRANSPORT_RCCL) {
-    NCCL_TRY(g_rccl.GroupStart());
+  if (c->transport_eff == TRANSPORT_PEER) {
+    const uint32_t seq = c->halo_seq + 1;
     for (Slab &s : c->slabs) {
+      if (!s.south.connected || !s.north.connected)
+        return fail(LBM_ERR_STATE, "peer transport: the ring neighbours are not connected (lbm_connect_peers)");
+      if (set_dev(s)) return LBM_ERR_HIP;
       const size_t count = (size_t)s.row0 * s.row_stride;
-      const int north = (s.index + 1) % P, south = (s.index + P - 1) % P;
       float *g = s.cells[buf];
-      NCCL_TRY(g_rccl.Send(g + (size_t)s.rows * s.row_stride, count, ncclFloat, north, s.comm, s.s_edge));
-      NCCL_TRY(g_rccl.Send(g + (size_t)s.row0 * s.row_stride, count, ncclFloat, south, s.comm, s.s_edge));
-      NCCL_TRY(g_rccl.Recv(g, count, ncclFloat, south, s.comm, s.s_edge));
-      NCCL_TRY(g_rccl.Recv(g + (size_t)(s.row0 + s.rows) * s.row_stride, count, ncclFloat, north, s.comm, s.s_edge));
+      PushArgs a{};
+      a.src_lo = g + (size_t)s.row0 * s.row_stride;                              // my bottom rows -> south's top halo
+      a.dst_lo = s.south.cells[buf] + (size_t)(s.row0 + s.south.rows) * s.row_stride;
+      a.src_hi = g + (size_t)s.rows * s.row_stride;                              // my top rows -> north's bottom halo
+      a.dst_hi = s.north.cells[buf];
+      a.n4 = count / 4;
+      a.flag_lo = s.south.flags + 1;  // I am the south neighbour's NORTH neighbour
+      a.flag_hi = s.north.flags + 0;
+      a.seq = seq;
+      a.ticket = s.halo_flags + 3;
+      // enough workgroups to move the rows in a few microseconds without taking the chip from the interior launch
+      const int per_side = (int)std::max<size_t>(1, std::min<size_t>(64, (a.n4 + 4 * kBlock - 1) / (4 * kBlock)));
+      hipLaunchKernelGGL(halo_push, dim3(2 * per_side), dim3(kBlock), 0, on_main ? s.s_main : s.s_edge, a);
+      HIP_TRY(hipGetLastError());
     }
-    NCCL_TRY(g_rccl.GroupEnd());
+    c->halo_seq = seq;
+  } else if (c->transport_eff == TRANSPORT_RCCL) {
+    std::vector<HaloBlock> blocks;
+    for (Slab &s : c->slabs) {
+      float *g = s.cells[buf];
+      HaloBlock b{};
+      b.count = (size_t)s.row0 * s.row_stride;
+      b.north = (s.index + 1) % P;
+      b.south = (s.index + P - 1) % P;
+      b.send_north = g + (size_t)s.rows * s.row_stride;
+      b.send_south = g + (size_t)s.row0 * s.row_stride;
+      b.recv_south = g;
+      b.recv_north = g + (size_t)(s.row0 + s.rows) * s.row_stride;
+      b.comm = s.comm;
+      b.stream = s.s_edge;
+      blocks.push_back(b);
+    }
+    RcclTransport t;
+    const char *op = nullptr;
+    if (int rc = ring_exchange(t, blocks.data(), (int)blocks.size(), &op))
+      return fail(LBM_ERR_COMM, "RCCL error during halo exchange (%s): %s", op ? op : "?",
+                  g_rccl.GetErrorString ? g_rccl.GetErrorString((ncclResult_t)rc) : "?");
   } else {
     // one process: each slab pulls from its neighbours once their edge launches are done
     for (Slab &s : c->slabs) {
@@ -707,8 +815,11 @@ int exchange_halos(lbm_ctx *c, int buf, int evq) {
   return LBM_OK;
 }
 
-int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
+int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launched) {
   if (nsteps < 0) return fail(LBM_ERR_ARG, "nsteps must be >= 0");
+  if (c->failed) return fail(LBM_ERR_STATE, "an earlier run failed after its launches had begun; destroy the context");
+  if (c->halo_mode && c->transport_eff == TRANSPORT_AUTO)
+    return fail(LBM_ERR_STATE, "rank context without a transport: pass a comm_id to lbm_create_rank or call lbm_connect_peers");
   if (c->steps_done + nsteps > c->p.max_iters)
     return fail(LBM_ERR_STATE, "av_vels record holds max_iters=%d steps; %d done, %d more requested", c->p.max_iters,
                 c->steps_done, nsteps);
@@ -722,6 +833,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
 
   // prologue: accelerate_flow of the first step on the current grid (kernels.cl:9-53); later
   // steps get theirs fused into the previous launch's write of row ny-2
+  *launched = true;
   for (Slab &s : c->slabs) {
     if (set_dev(s)) return LBM_ERR_HIP;
     if (multi) HIP_TRY(hipStreamSynchronize(s.s_edge));
@@ -731,6 +843,8 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       HIP_TRY(hipGetLastError());
     }
   }
+  // compact launch sets (small slabs, peer transport): everything on the main stream
+  const bool compact = compact_sets(c);
   if (multi) {
     // halos of the initial state ("launch set -1", event parity 1)
     for (Slab &s : c->slabs) {
@@ -739,12 +853,12 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       HIP_TRY(hipEventRecord(s.ev_edgek[1], s.s_main));
       HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[1], 0));
     }
-    if (int rc = exchange_halos(c, c->cur, 1)) return rc;
+    if (int rc = exchange_halos(c, c->cur, 1, compact)) return rc;
   }
   if (timed)
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
-      if (multi) {
+      if (multi && !compact) {
         // start the clock on the main stream once the initial halos have landed
         HIP_TRY(hipEventRecord(s.ev_aux, s.s_edge));
         HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_aux, 0));
@@ -763,7 +877,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     if (fill == 0) return LBM_OK;
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
-      if (multi) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[last_q], 0));
+      if (multi && !compact) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[last_q], 0));
       int used = s.nb_main + s.nb_edge;
       if (batch_kind == KIND_FUSED2) used = s.f_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED3) used = s.f3_main.units + (multi ? s.f_edge.units : 0);
@@ -772,7 +886,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
       HIP_TRY(hipGetLastError());
-      if (multi) {
+      if (multi && !compact) {
         // the next batch's edge launches overwrite ring slots: order them after this reduction
         HIP_TRY(hipEventRecord(s.ev_aux, s.s_main));
         HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_aux, 0));
@@ -783,6 +897,12 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
     return LBM_OK;
   };
 
+  // lbm_run_profiled: timing events around the launches of the first local slab
+  auto mark = [&](const Slab &s, int which, hipStream_t st) -> int {
+    if (c->prof_sets < 0 || c->prof_sets >= kProfSets || &s != &c->slabs[0]) return LBM_OK;
+    HIP_TRY(hipEventRecord(c->prof_ev[(size_t)c->prof_sets * kProfEvents + which], st));
+    return LBM_OK;
+  };
   int i = 0, set = 0;
   while (i < nsteps) {
     const int src = c->cur;
@@ -811,6 +931,7 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       float *slot1 = s.partials + (size_t)c->ring_fill * s.nb_total;
       float *slot2 = slot1 + s.nb_total;
       if (!multi) {
+        if (int rc = mark(s, 3, s.s_main)) return rc;
         if (kind == KIND_MULTI) {
           MultiArgs a = base_args_multi(c, s, src, adv, !last);
           a.partials = slot1;
@@ -839,13 +960,46 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
           launch_step(c, a, s.nb_main, s.s_main);
         }
         HIP_TRY(hipGetLastError());
+        if (int rc = mark(s, 4, s.s_main)) return rc;
+        continue;
+      }
+      if (compact && kind == KIND_MULTI) {
+        // ---- compact launch set: wait for the neighbours' rows of the latest exchange, then ONE launch of all tile
+        // rows, the edge tile rows (tile row 0 and the tile rows from t_top up) first; they push this set's halo rows
+        if (int rc = wait_halos(c, s, s.s_main, c->halo_seq)) return rc;
+        const int m = s.m_tiles_y;
+        const int t_top = std::max(1, std::min(m, (s.rows - s.edge_rows) / s.m_ty));
+        const int edge_trows = 1 + (m - t_top);
+        MultiArgs a = base_args_multi(c, s, src, adv, !last);
+        a.partials = slot1;
+        a.ty_begin = 0; a.ty_split = 1; a.ty_begin2 = t_top;     // workgroup rows 1 .. edge_trows-1: tile rows t_top ..
+        a.ty_split2 = edge_trows; a.ty_begin3 = 1;               // then the interior tile rows 1 .. t_top-1
+        if (!last) {
+          a.push_rows = s.row0;
+          a.edge_blocks = edge_trows * s.m_tiles_x;
+          a.push_lo = s.south.cells[src ^ 1] + (size_t)(s.row0 + s.south.rows) * s.row_stride;
+          a.push_hi = s.north.cells[src ^ 1];
+          a.flag_lo = s.south.flags + 1;
+          a.flag_hi = s.north.flags + 0;
+          a.ticket = s.halo_flags + 3;
+          a.seq = c->halo_seq + 1;
+        }
+        if (int rc = mark(s, 3, s.s_main)) return rc;
+        launch_multi(s, a, m, s.s_main);
+        HIP_TRY(hipGetLastError());
+        if (int rc = mark(s, 4, s.s_main)) return rc;
         continue;
       }
       // ---- slab mode: edge rows first (they feed the neighbours), interior meanwhile ----
-      // edge launch: needs the previous set's halos (edge stream order) and interior (event)
+      // edge launch: needs the previous set's halos (edge stream order; with the peer transport the neighbours'
+      // pushes of the latest exchange, announced in this slab's flag words) and interior (event)
+      if (c->transport_eff == TRANSPORT_PEER)
+        if (int rc = wait_halos(c, s, s.s_edge, c->halo_seq)) return rc;
       HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
       // interior launch: needs the previous set's edge rows
       HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
+      if (int rc = mark(s, 0, s.s_edge)) return rc;
+      if (int rc = mark(s, 3, s.s_main)) return rc;
       if (kind == KIND_MULTI) {
         // edge = the tile rows that hold the halo_depth bottom and top rows (what the neighbours receive):
         // tile row 0 and the tile rows from t_top up; interior = tile rows 1 .. t_top-1
@@ -926,9 +1080,17 @@ int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
       }
       HIP_TRY(hipEventRecord(s.ev_edgek[q], s.s_edge));
       HIP_TRY(hipEventRecord(s.ev_main[q], s.s_main));
+      if (int rc = mark(s, 1, s.s_edge)) return rc;
+      if (int rc = mark(s, 4, s.s_main)) return rc;
     }
-    if (multi && !last)
-      if (int rc = exchange_halos(c, src ^ 1, q)) return rc;
+    if (multi && compact && kind == KIND_MULTI) {
+      if (!last) c->halo_seq++;     // the edge tiles of this set's launches have pushed exchange number halo_seq
+    } else if (multi) {
+      if (!last)
+        if (int rc = exchange_halos(c, src ^ 1, q, compact)) return rc;
+      if (int rc = mark(c->slabs[0], 2, compact ? c->slabs[0].s_main : c->slabs[0].s_edge)) return rc;
+    }
+    if (c->prof_sets >= 0) c->prof_sets++;
     c->cur ^= 1;
     c->ring_fill += adv;
     i += adv;
@@ -961,8 +1123,36 @@ int sync_all(lbm_ctx *c) {
     if (set_dev(s)) return LBM_ERR_HIP;
     if (s.s_edge) HIP_TRY(hipStreamSynchronize(s.s_edge));
     HIP_TRY(hipStreamSynchronize(s.s_main));
+    if (c->transport_eff == TRANSPORT_PEER && s.halo_flags) {
+      uint32_t err = 0;
+      HIP_TRY(hipMemcpy(&err, s.halo_flags + 2, sizeof err, hipMemcpyDeviceToHost));
+      if (err) {
+        c->failed = true;
+        return fail(LBM_ERR_COMM, "peer transport: slab %d waited %d s for a neighbour's halo rows that never came", s.index,
+                    (int)(kHaloWaitTicks / 100000000ull));
+      }
+    }
   }
   return LBM_OK;
+}
+
+// A failure after launches have begun leaves kernels, events and possibly a half-built exchange behind: let what was
+// enqueued finish (so that lbm_destroy's stream synchronisation returns) and refuse further work on the context.
+int run_steps(lbm_ctx *c, int nsteps, bool timed, double *ms) {
+  bool launched = false;
+  const int rc = run_steps_impl(c, nsteps, timed, ms, &launched);
+  if (rc != LBM_OK && launched) {
+    const std::string keep = g_err;
+    for (Slab &s : c->slabs) {
+      hipSetDevice(s.dev);
+      if (s.s_edge) (void)hipStreamSynchronize(s.s_edge);
+      if (s.s_main) (void)hipStreamSynchronize(s.s_main);
+    }
+    (void)hipGetLastError();
+    c->failed = true;
+    g_err = keep;
+  }
+  return rc;
 }
 
 void free_slab(Slab &s) {
@@ -983,6 +1173,14 @@ void free_slab(Slab &s) {
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
+  for (PeerLink *l : {&s.south, &s.north}) {
+    if (!l->ipc) continue;
+    for (int i = 0; i < 2; i++)
+      if (l->cells[i]) hipIpcCloseMemHandle(l->cells[i]);
+    if (l->flags) hipIpcCloseMemHandle(l->flags);
+  }
+  if (s.halo_flags) hipFree(s.halo_flags);
+  if (s.av_tmp) hipFree(s.av_tmp);
   if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
   if (s.s_edge) hipStreamDestroy(s.s_edge);
   if (s.s_main) hipStreamDestroy(s.s_main);
@@ -1021,8 +1219,7 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   s.ext_rows = s.rows + 2 * s.row0;
   // row-interleaved SoA (see d2q9_kernels.h): plane-rows padded to whole 256-B lines
   s.plane_stride = ((size_t)(nx + 63) / 64) * 64;
-  const char *pad_env = getenv("LBM_ROW_PAD");  // extra floats between grid rows (tuning only)
-  s.row_stride = 9 * s.plane_stride + (pad_env ? (size_t)atol(pad_env) / 4 * 4 : 0);
+  s.row_stride = 9 * s.plane_stride;
   for (int i = 0; i < 2; i++) {
     if (dev_alloc(&s.cells[i], s.row_stride * s.ext_rows + 64)) return LBM_ERR_HIP;
     HIP_TRY(hipMemset(s.cells[i], 0, (s.row_stride * s.ext_rows + 64) * sizeof(float)));
@@ -1049,6 +1246,10 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
     else s.accel_ext_b = e;
   }
   if (dev_alloc(&s.av_sum, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
+  if (multi) {
+    if (dev_alloc(&s.halo_flags, 64)) return LBM_ERR_HIP;
+    HIP_TRY(hipMemset(s.halo_flags, 0, 64 * sizeof(uint32_t)));
+  }
   s.fin_blocks = std::max(1, std::min(div_up((long)nx * s.rows, kBlock), 2048));
   if (dev_alloc(&s.fin_partials, (size_t)s.fin_blocks)) return LBM_ERR_HIP;
   return LBM_OK;
@@ -1079,10 +1280,148 @@ int rebuild_geometry(lbm_ctx *c) {
   return alloc_partials(c);
 }
 
+// ---- peer-halo transport: connecting the ring -------------------------------------------------------
+void fill_peer_info(const Slab &s, PeerInfoBlob &b, bool with_ipc, hipError_t *ipc_err) {
+  memset(&b, 0, sizeof b);
+  b.magic = kPeerMagic;
+  b.pid = (int32_t)getpid();
+  b.device = s.dev;
+  b.rows = s.rows;
+  b.row0 = s.row0;
+  b.row_stride = s.row_stride;
+  b.cells_ptr[0] = (uint64_t)(uintptr_t)s.cells[0];
+  b.cells_ptr[1] = (uint64_t)(uintptr_t)s.cells[1];
+  b.flags_ptr = (uint64_t)(uintptr_t)s.halo_flags;
+  if (with_ipc) {
+    hipError_t e = hipIpcGetMemHandle(&b.cells[0], s.cells[0]);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&b.cells[1], s.cells[1]);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&b.flags, s.halo_flags);
+    if (ipc_err) *ipc_err = e;
+  }
+}
+
+int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *which) {
+  if (info.magic != kPeerMagic) return fail(LBM_ERR_ARG, "%s neighbour: not a peer descriptor of this library version", which);
+  if (info.row_stride != s.row_stride || info.row0 != s.row0)
+    return fail(LBM_ERR_ARG, "%s neighbour stores its rows differently (row stride %llu / %llu floats, halo depth %d / %d): all ranks must "
+                "be created with the same params and defaults", which, (unsigned long long)info.row_stride,
+                (unsigned long long)s.row_stride, info.row0, s.row0);
+  if (set_dev(s)) return LBM_ERR_HIP;
+  l = PeerLink{};
+  l.rows = info.rows;
+  if (info.pid == (int32_t)getpid()) {
+    // same process: the pointers are valid here; another device needs peer access
+    if (info.device != s.dev) {
+      int can = 0;
+      HIP_TRY(hipDeviceCanAccessPeer(&can, s.dev, info.device));
+      if (!can) return fail(LBM_ERR_COMM, "device %d cannot access device %d as a peer", s.dev, info.device);
+      hipError_t e = hipDeviceEnablePeerAccess(info.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return fail(LBM_ERR_HIP, "hipDeviceEnablePeerAccess(%d) from device %d: %s", info.device, s.dev, hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+    l.cells[0] = (float *)(uintptr_t)info.cells_ptr[0];
+    l.cells[1] = (float *)(uintptr_t)info.cells_ptr[1];
+    l.flags = (uint32_t *)(uintptr_t)info.flags_ptr;
+  } else {
+    void *p0 = nullptr, *p1 = nullptr, *pf = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p0, info.cells[0], hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(&p1, info.cells[1], hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf, info.flags, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      if (p0) hipIpcCloseMemHandle(p0);
+      if (p1) hipIpcCloseMemHandle(p1);
+      (void)hipGetLastError();
+      return fail(LBM_ERR_COMM, "hipIpcOpenMemHandle of the %s neighbour's grids (process %d, device %d): %s", which, info.pid,
+                  info.device, hipGetErrorString(e));
+    }
+    l.cells[0] = (float *)p0;
+    l.cells[1] = (float *)p1;
+    l.flags = (uint32_t *)pf;
+    l.ipc = true;
+  }
+  l.connected = true;
+  return LBM_OK;
+}
+
+// one process: every slab's neighbours are local slabs
+int connect_local_ring(lbm_ctx *c) {
+  const int P = (int)c->slabs.size();
+  for (Slab &s : c->slabs) {
+    PeerInfoBlob so, no;
+    fill_peer_info(c->slabs[(s.index + P - 1) % P], so, false, nullptr);
+    fill_peer_info(c->slabs[(s.index + 1) % P], no, false, nullptr);
+    if (int rc = connect_link(s, s.south, so, "south")) return rc;
+    if (int rc = connect_link(s, s.north, no, "north")) return rc;
+  }
+  return LBM_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
 extern "C" {
+
+int lbm_set_default(const char *key, long value) {
+  if (!key) return fail(LBM_ERR_ARG, "NULL argument");
+  if (!strcmp(key, "force_halo")) {
+    if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "force_halo must be 0 or 1");
+    g_defaults.force_halo = (int)value;
+  } else if (!strcmp(key, "halo_depth")) {
+    if (value != 0 && (value < 2 || value > kMultiMaxT)) return fail(LBM_ERR_ARG, "halo_depth must be 0 (auto) or 2..%d", kMultiMaxT);
+    g_defaults.halo_depth = (int)value;
+  } else if (!strcmp(key, "transport")) {
+    if (value < TRANSPORT_AUTO || value > TRANSPORT_PEER) return fail(LBM_ERR_ARG, "transport must be 0 (auto), 1 (rccl), 2 (copy) or 3 (peer)");
+    g_defaults.transport = (int)value;
+  } else if (!strcmp(key, "lanes_out")) {
+    if (value != 0 && (value < 4 || value > 62)) return fail(LBM_ERR_ARG, "lanes_out must be 0 (auto) or 4..62");
+    g_defaults.lanes_out = (int)value;
+  } else {
+    return fail(LBM_ERR_ARG, "unknown default '%s'", key);
+  }
+  return LBM_OK;
+}
+
+size_t lbm_peer_info_size(void) { return sizeof(PeerInfoBlob); }
+
+int lbm_peer_info(lbm_ctx *c, void *info_out) {
+  if (!c || !info_out) return fail(LBM_ERR_ARG, "NULL argument");
+  if (!c->halo_mode || c->slabs.size() != 1)
+    return fail(LBM_ERR_STATE, "peer descriptors exist for rank contexts (one local slab that exchanges halo rows)");
+  Slab &s = c->slabs[0];
+  if (set_dev(s)) return LBM_ERR_HIP;
+  PeerInfoBlob b;
+  hipError_t e = hipSuccess;
+  fill_peer_info(s, b, true, &e);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(LBM_ERR_HIP, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+  }
+  memcpy(info_out, &b, sizeof b);
+  return LBM_OK;
+}
+
+int lbm_connect_peers(lbm_ctx *c, const void *south_info, const void *north_info) {
+  if (!c || !south_info || !north_info) return fail(LBM_ERR_ARG, "NULL argument");
+  if (!c->halo_mode || c->slabs.size() != 1) return fail(LBM_ERR_STATE, "lbm_connect_peers is for rank contexts");
+  if (int rc = sync_all(c)) return rc;
+  Slab &s = c->slabs[0];
+  PeerInfoBlob so, no;
+  memcpy(&so, south_info, sizeof so);
+  memcpy(&no, north_info, sizeof no);
+  PeerLink south, north;
+  if (int rc = connect_link(s, south, so, "south")) return rc;
+  if (so.pid == no.pid && so.cells_ptr[0] == no.cells_ptr[0]) {
+    north = south;      // a ring of one or two: the same neighbour on both sides, mapped once
+    north.ipc = false;
+  } else if (int rc = connect_link(s, north, no, "north")) {
+    return rc;
+  }
+  s.south = south;
+  s.north = north;
+  c->transport_eff = TRANSPORT_PEER;
+  return LBM_OK;
+}
 
 const char *lbm_last_error(void) { return g_err.c_str(); }
 const char *lbm_version(void) { return "lbm-hip 0.1 (gfx950)"; }
@@ -1106,7 +1445,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
   if (int rc = check_params(params)) return rc;
   if (!obstacles) return fail(LBM_ERR_ARG, "obstacles is NULL");
   if (nslabs_global < 1) return fail(LBM_ERR_ARG, "need at least one slab");
-  if ((nslabs_global > 1 || (getenv("LBM_FORCE_HALO") && atoi(getenv("LBM_FORCE_HALO")))) && params->ny / nslabs_global < 4)
+  if ((nslabs_global > 1 || g_defaults.force_halo) && params->ny / nslabs_global < 4)
     return fail(LBM_ERR_ARG, "ny=%d gives fewer than 4 rows per slab over %d slabs", params->ny, nslabs_global);
   int ndev_visible = 0;
   HIP_TRY(hipGetDeviceCount(&ndev_visible));
@@ -1117,10 +1456,9 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
   lbm_ctx *c = new lbm_ctx();
   c->p = *params;
   c->nslabs_global = nslabs_global;
-  // LBM_FORCE_HALO=1 runs even a single slab through the halo-exchange machinery (a ring of one: the slab
-  // is its own north and south neighbour) — lets a 1-GPU box exercise the RCCL transport end to end
-  const char *force = getenv("LBM_FORCE_HALO");
-  c->halo_mode = nslabs_global > 1 || (force && atoi(force) != 0);
+  // default "force_halo" runs even a single slab through the halo-exchange machinery (a ring of one: the slab
+  // is its own north and south neighbour) — lets a 1-GPU box exercise every transport end to end
+  c->halo_mode = nslabs_global > 1 || g_defaults.force_halo != 0;
   {
     // halo depth: small slabs are launch-bound and use the LDS multi-step kernel with 8 steps per exchange
     const int rows_min = params->ny / nslabs_global;
@@ -1129,7 +1467,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     // ... slabs of 2M cells and more depth 4 (four-steps-per-launch kernel), the others depth 3 (three-step kernel)
     const bool big = (long)params->nx * rows_min >= (2L << 20);
     c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : (big ? 4 : (rows_min >= 6 ? 3 : 2));
-    if (const char *hd = getenv("LBM_HALO_DEPTH")) c->halo_depth = std::max(2, std::min(kMultiMaxT, atoi(hd)));
+    if (g_defaults.halo_depth > 0) c->halo_depth = g_defaults.halo_depth;
     if (rows_min < 2 * c->halo_depth) c->halo_depth = 2;
   }
   c->rank_mode = rank_mode;
@@ -1151,33 +1489,41 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     bool dup = false;
     for (size_t i = 0; i < devs.size(); i++)
       for (size_t j = i + 1; j < devs.size(); j++) dup |= devs[i] == devs[j];
-    const char *env = getenv("LBM_TRANSPORT");
-    int want = TRANSPORT_AUTO;
-    if (env && !strcmp(env, "rccl")) want = TRANSPORT_RCCL;
-    if (env && !strcmp(env, "copy")) want = TRANSPORT_COPY;
-    if (rank_mode) c->transport_eff = (want == TRANSPORT_COPY && nslabs_global == 1) ? TRANSPORT_COPY : TRANSPORT_RCCL;
-    else if (want == TRANSPORT_AUTO) c->transport_eff = dup ? TRANSPORT_COPY : TRANSPORT_RCCL;
-    else c->transport_eff = want;
-    if (c->transport_eff == TRANSPORT_RCCL && !rank_mode && dup) {
-      rc = fail(LBM_ERR_ARG, "RCCL transport needs distinct devices per slab");
-    } else if (c->transport_eff == TRANSPORT_RCCL) {
+    const int want = g_defaults.transport;
+    const bool whole_ring_local = (int)c->slabs.size() == nslabs_global;
+    if (rank_mode && comm_id) {
+      // a communicator: RCCL send/recv until (unless) the caller connects the peers; the all-reduce of the velocity
+      // record uses it either way
       rc = load_rccl();
       if (rc == LBM_OK) {
-        if (rank_mode) {
-          ncclUniqueId id;
-          memcpy(&id, comm_id, sizeof id);
-          hipSetDevice(c->slabs[0].dev);
-          ncclResult_t r = g_rccl.CommInitRank(&c->slabs[0].comm, nslabs_global, id, rank);
-          if (r != ncclSuccess) rc = fail(LBM_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
-        } else {
+        ncclUniqueId id;
+        memcpy(&id, comm_id, sizeof id);
+        hipSetDevice(c->slabs[0].dev);
+        ncclResult_t r = g_rccl.CommInitRank(&c->slabs[0].comm, nslabs_global, id, rank);
+        if (r != ncclSuccess) rc = fail(LBM_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+      }
+      c->transport_eff = TRANSPORT_RCCL;
+      if (rc == LBM_OK && whole_ring_local && want == TRANSPORT_PEER) {
+        rc = connect_local_ring(c);
+        if (rc == LBM_OK) c->transport_eff = TRANSPORT_PEER;
+      }
+    } else if (!whole_ring_local) {
+      c->transport_eff = TRANSPORT_AUTO;  // rank of a larger ring without communicator: lbm_connect_peers decides
+    } else if (want == TRANSPORT_RCCL) {
+      if (dup) {
+        rc = fail(LBM_ERR_ARG, "RCCL transport needs distinct devices per slab");
+      } else {
+        rc = load_rccl();
+        if (rc == LBM_OK) {
           std::vector<ncclComm_t> comms(devs.size());
           ncclResult_t r = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
           if (r != ncclSuccess) rc = fail(LBM_ERR_COMM, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
           else
             for (size_t i = 0; i < devs.size(); i++) c->slabs[i].comm = comms[i];
         }
+        c->transport_eff = TRANSPORT_RCCL;
       }
-    } else {
+    } else if (want == TRANSPORT_COPY) {
       // device-to-device copies: enable peer access between distinct devices
       for (size_t i = 0; i < devs.size(); i++)
         for (size_t j = 0; j < devs.size(); j++)
@@ -1186,6 +1532,11 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
             hipError_t e = hipDeviceEnablePeerAccess(devs[j], 0);
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
           }
+      c->transport_eff = TRANSPORT_COPY;
+    } else {
+      // all slabs in this process: direct stores into the neighbours' halo rows
+      rc = connect_local_ring(c);
+      c->transport_eff = TRANSPORT_PEER;
     }
   }
   if (rc == LBM_OK) {
@@ -1224,9 +1575,9 @@ int lbm_create(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles
 int lbm_create_rank(lbm_ctx **out, const lbm_params *params, const int32_t *obstacles, int rank, int nranks, int device,
                     const void *comm_id) {
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(LBM_ERR_ARG, "bad rank %d of %d", rank, nranks);
-  if (nranks > 1 && !comm_id) return fail(LBM_ERR_ARG, "comm_id is NULL");
   std::vector<int> idx{rank}, devs{device};
-  // rank mode proper needs a communicator; a single rank gets one too when an id is supplied (self-ring tests)
+  // with a comm_id the rank gets an RCCL communicator (a single rank too: self-ring tests); without one it has to
+  // be connected to its ring neighbours with lbm_connect_peers and returns per-rank velocity sums
   return create_common(out, params, obstacles, nranks, idx, devs, nranks > 1 || comm_id != nullptr, rank, comm_id);
 }
 
@@ -1267,6 +1618,53 @@ int lbm_run(lbm_ctx *c, int nsteps) {
 int lbm_run_timed(lbm_ctx *c, int nsteps, double *ms) {
   if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
   return run_steps(c, nsteps, true, ms);
+}
+
+int lbm_run_profiled(lbm_ctx *c, int nsteps, double *stats) {
+  if (!c || !stats) return fail(LBM_ERR_ARG, "NULL argument");
+  for (int i = 0; i < 8; i++) stats[i] = 0.0;
+  if (c->slabs.empty()) return fail(LBM_ERR_STATE, "no slab");
+  if (set_dev(c->slabs[0])) return LBM_ERR_HIP;
+  while (c->prof_ev.size() < (size_t)kProfSets * kProfEvents) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    c->prof_ev.push_back(e);
+  }
+  if (int rc = sync_all(c)) return rc;
+  c->prof_sets = 0;
+  const int before = c->steps_done;
+  int rc = run_steps(c, nsteps, false, nullptr);
+  const int sets_run = c->prof_sets;
+  const int sets = std::min(sets_run, kProfSets);
+  c->prof_sets = -1;
+  if (rc == LBM_OK) rc = sync_all(c);
+  if (rc != LBM_OK) return rc;
+  if (sets < 1) return LBM_OK;
+  auto ev = [&](int set, int which) { return c->prof_ev[(size_t)set * kProfEvents + which]; };
+  auto span = [&](hipEvent_t a, hipEvent_t b, double *acc) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess) *acc += ms * 1e3;
+    else (void)hipGetLastError();
+  };
+  double edge = 0, xchg = 0, inner = 0, lag = 0, period = 0;
+  for (int k = 0; k < sets; k++) {
+    span(ev(k, 3), ev(k, 4), &inner);
+    if (c->halo_mode) {
+      span(ev(k, 0), ev(k, 1), &edge);
+      span(ev(k, 1), ev(k, 2), &xchg);
+      span(ev(k, 0), ev(k, 3), &lag);
+    }
+  }
+  if (sets > 1) span(ev(0, 3), ev(sets - 1, 3), &period);
+  stats[0] = sets;
+  stats[1] = (double)(c->steps_done - before) / std::max(1, sets_run);
+  stats[2] = edge / sets;
+  stats[3] = xchg / sets;
+  stats[4] = inner / sets;
+  stats[5] = sets > 1 ? period / (sets - 1) : 0.0;
+  stats[6] = lag / sets;
+  stats[7] = c->transport_eff;
+  return LBM_OK;
 }
 
 int lbm_sync(lbm_ctx *c) {
@@ -1313,22 +1711,18 @@ int lbm_download(lbm_ctx *c, float *cells_out, float *av_vels_out) {
   if (av_vels_out && c->steps_done > 0) {
     const int T = c->steps_done;
     std::vector<double> total(T, 0.0);
-    if (c->rank_mode && c->halo_mode && c->transport_eff == TRANSPORT_RCCL) {
-      // combine the per-rank velocity sums: one all-reduce over the whole record
+    if (c->rank_mode && c->slabs[0].comm) {
+      // combine the per-rank velocity sums: one all-reduce over the whole record (into a buffer kept for later calls)
       Slab &s = c->slabs[0];
       if (set_dev(s)) return LBM_ERR_HIP;
-      double *tmp = nullptr;
-      if (dev_alloc(&tmp, (size_t)T)) return LBM_ERR_HIP;
-      ncclResult_t r = g_rccl.AllReduce(s.av_sum, tmp, (size_t)T, ncclDouble, ncclSum, s.comm, s.s_main);
-      if (r != ncclSuccess) {
-        hipFree(tmp);
-        return fail(LBM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
-      }
-      hipError_t e = hipMemcpyAsync(total.data(), tmp, sizeof(double) * T, hipMemcpyDeviceToHost, s.s_main);
+      if (!s.av_tmp && dev_alloc(&s.av_tmp, (size_t)std::max(1, c->p.max_iters))) return LBM_ERR_HIP;
+      ncclResult_t r = g_rccl.AllReduce(s.av_sum, s.av_tmp, (size_t)T, ncclDouble, ncclSum, s.comm, s.s_main);
+      if (r != ncclSuccess) return fail(LBM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
+      hipError_t e = hipMemcpyAsync(total.data(), s.av_tmp, sizeof(double) * T, hipMemcpyDeviceToHost, s.s_main);
       if (e == hipSuccess) e = hipStreamSynchronize(s.s_main);
-      hipFree(tmp);
       if (e != hipSuccess) return fail(LBM_ERR_HIP, "HIP error reading av_vels: %s", hipGetErrorString(e));
     } else {
+      // (a rank without communicator returns the sums over ITS rows: the caller adds the ranks' records)
       for (Slab &s : c->slabs) {
         if (set_dev(s)) return LBM_ERR_HIP;
         HIP_TRY(hipMemcpy(c->av_host, s.av_sum, sizeof(double) * T, hipMemcpyDeviceToHost));
@@ -1349,17 +1743,17 @@ int lbm_final_state(lbm_ctx *c, float *u_x, float *u_y, float *u, float *pressur
   for (Slab &s : c->slabs) {
     if (set_dev(s)) return LBM_ERR_HIP;
     const size_t n = (size_t)nx * s.rows;
+    // the four columns go to the grid that is not current — scratch between runs, 9 n floats of room (as in
+    // lbm_download): no allocation inside the reference-rule timed region (d2q9-bgk.c:196-263)
     float *d[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; i++)
-      if (outs[i] && dev_alloc(&d[i], n)) return LBM_ERR_HIP;
+      if (outs[i]) d[i] = s.cells[c->cur ^ 1] + (size_t)i * n;
     hipLaunchKernelGGL(final_fields, dim3(s.fin_blocks), dim3(kBlock), 0, s.s_main, s.own(c->cur), s.plane_stride,
                        s.row_stride, nx, s.mask_own(nx), n, c->p.density, d[0], d[1], d[2], d[3], s.fin_partials);
     hipError_t e = hipGetLastError();
     for (int i = 0; i < 4 && e == hipSuccess; i++)
       if (outs[i]) e = hipMemcpyAsync(outs[i] + (size_t)s.y0 * nx, d[i], n * sizeof(float), hipMemcpyDeviceToHost, s.s_main);
     if (e == hipSuccess) e = hipStreamSynchronize(s.s_main);
-    for (int i = 0; i < 4; i++)
-      if (d[i]) hipFree(d[i]);
     if (e != hipSuccess) return fail(LBM_ERR_HIP, "HIP error in output stage: %s", hipGetErrorString(e));
   }
   return LBM_OK;
@@ -1381,7 +1775,7 @@ int lbm_reynolds(lbm_ctx *c, float *reynolds_out) {
     HIP_TRY(hipStreamSynchronize(s.s_main));
     for (float v : part) tot += v;
   }
-  if (c->rank_mode && c->halo_mode && c->transport_eff == TRANSPORT_RCCL) {
+  if (c->rank_mode && c->slabs[0].comm) {
     Slab &s = c->slabs[0];
     double *tmp = nullptr;
     if (dev_alloc(&tmp, 2)) return LBM_ERR_HIP;
@@ -1434,6 +1828,41 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     (key[0] == 'w' ? c->windows : (key[0] == 'l' ? c->load_bufs : c->sched_waves)) = (int)value;
     return rebuild_geometry(c);
   }
+  if (!strcmp(key, "transport")) {
+    // halo transport of a context that has both: every rank of the ring must make the same call at the same point
+    if (!c->halo_mode) return fail(LBM_ERR_STATE, "a context without halo rows has no transport");
+    if (int rc = sync_all(c)) return rc;
+    if (value == TRANSPORT_RCCL) {
+      for (const Slab &s : c->slabs)
+        if (!s.comm) return fail(LBM_ERR_STATE, "no RCCL communicator: create the context with a comm_id (or default transport 1)");
+    } else if (value == TRANSPORT_PEER) {
+      for (const Slab &s : c->slabs)
+        if (!s.south.connected || !s.north.connected) return fail(LBM_ERR_STATE, "peers are not connected (lbm_connect_peers)");
+    } else {
+      return fail(LBM_ERR_ARG, "transport must be 1 (RCCL send/recv) or 3 (peer stores)");
+    }
+    c->transport_eff = (int)value;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "compact")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "compact must be -1 (auto), 0 or 1");
+    if (int rc = sync_all(c)) return rc;
+    c->compact = (int)value;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "halo_sync")) {
+    if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "halo_sync must be 0 (wait kernel) or 1 (hipStreamWaitValue32)");
+    if (value == 1) {
+      int can = 0;
+      for (const Slab &s : c->slabs) {
+        HIP_TRY(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, s.dev));
+        if (!can) return fail(LBM_ERR_STATE, "device %d cannot wait on memory values", s.dev);
+      }
+    }
+    if (int rc = sync_all(c)) return rc;
+    c->halo_sync = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "multistep")) {
     if (value < -1 || value > kMultiMaxT) return fail(LBM_ERR_ARG, "multistep must be -1..%d", kMultiMaxT);
     c->multistep = (int)value;
@@ -1469,6 +1898,9 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
+  else if (!strcmp(key, "halo_sync")) *value = c->halo_sync;
+  else if (!strcmp(key, "compact")) *value = compact_sets(c);
+  else if (!strcmp(key, "halo_depth")) *value = c->halo_mode ? c->halo_depth : 0;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;
   else return fail(LBM_ERR_ARG, "unknown option '%s'", key);
   return LBM_OK;
@@ -1525,6 +1957,7 @@ void lbm_destroy(lbm_ctx *c) {
     if (s.s_main) hipStreamSynchronize(s.s_main);
     if (s.s_edge) hipStreamSynchronize(s.s_edge);
   }
+  for (hipEvent_t e : c->prof_ev) hipEventDestroy(e);
   for (Slab &s : c->slabs) free_slab(s);
   free(c->av_host);
   delete c;

@@ -1,6 +1,10 @@
-"""Helper of test_gpu_parity.py::test_rccl_transport_self_ring — run as a subprocess (so that a hang in
-the communication layer is a test failure, not a stuck test session).  One rank, LBM_FORCE_HALO=1: the
-slab is its own north and south neighbour and every halo exchange is an RCCL send/recv to self."""
+"""Helper of test_gpu_parity.py::test_transport_self_ring — run as a subprocess (so that a hang in the
+communication layer is a test failure, not a stuck test session).  One rank with the default "force_halo": the
+slab is its own north and south neighbour and every halo exchange goes through the chosen transport to itself:
+  rccl   ncclSend/ncclRecv on a communicator made by ncclCommInitRank, av_vels through ncclAllReduce
+  copy   device-to-device hipMemcpyAsync between the slab's own rows
+  peer   halo_push kernel + flag words, consumer side by wait kernel (halo_sync 0) and by hipStreamWaitValue32 (1);
+         once on a context that also has a communicator (lbm_connect_peers on top of RCCL, switched back and forth)"""
 import os
 import sys
 
@@ -9,7 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lbm_amd
 
-transport = sys.argv[1]  # "rccl" or "copy"
+transport = sys.argv[1]  # "rccl", "copy" or "peer"
 rng = np.random.default_rng(21)
 nx, ny, nsteps = 512, 96, 23
 ob = (rng.random((ny, nx)) < 0.05).astype(np.int32)
@@ -26,19 +30,47 @@ with lbm_amd.LBM(p, ob) as sim:
     ref, av_ref = sim.download()
     re_ref = sim.reynolds()
 
-os.environ["LBM_FORCE_HALO"] = "1"
-os.environ["LBM_TRANSPORT"] = transport
-for (fuse, ms) in ((0, 0), (1, 0), (3, 0), (4, 0), (0, 8), (0, 5)):  # 1 / 2 / 3 / 4 / 8 / 5 timesteps per launch set (halo depth 8)
-    kw = dict(rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) if transport == "rccl" else dict(devices=[0])
-    with lbm_amd.LBM(p, ob, **kw) as sim:
-        assert sim.get_option("transport") == (1 if transport == "rccl" else 2)
-        sim.set_option("fuse", fuse)
-        sim.set_option("multistep", ms)
+lbm_amd.set_default("force_halo", 1)
+lbm_amd.set_default("transport", transport)
+code = lbm_amd.TRANSPORTS[transport]
+# peer: consumer-side wait by kernel / by hipStreamWaitValue32, and the launch sets of d2q9_multi compact (one launch,
+# the edge tiles push the halo rows themselves) / as edge launch + interior launch + push kernel
+variants = ((0, -1), (1, -1), (0, 0)) if transport == "peer" else ((0, -1),)
+for (sync, compact) in variants:
+    for (fuse, ms) in ((0, 0), (1, 0), (3, 0), (4, 0), (0, 8), (0, 5)):  # 1 / 2 / 3 / 4 / 8 / 5 timesteps per launch set (halo depth 8)
+        kw = dict(rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) if transport == "rccl" else dict(devices=[0])
+        with lbm_amd.LBM(p, ob, **kw) as sim:
+            assert sim.get_option("transport") == code
+            if transport == "peer":
+                sim.set_option("halo_sync", sync)
+                sim.set_option("compact", compact)
+            sim.set_option("fuse", fuse)
+            sim.set_option("multistep", ms)
+            if transport == "peer":
+                assert sim.get_option("compact") == (1 if (ms and compact) else 0)
+            sim.upload(cells0)
+            sim.run(nsteps)
+            got, av = sim.download()   # rank mode: av_vels go through ncclAllReduce
+            re = sim.reynolds()
+        assert np.array_equal(got, ref), "state differs (transport %s, fuse %d, multistep %d)" % (transport, fuse, ms)
+        assert np.max(np.abs(av - av_ref) / av_ref) < 2e-6
+        assert abs(re / re_ref - 1) < 1e-5
+
+if transport == "peer":
+    # a rank context with a communicator AND connected peers: starts on RCCL, connects to itself through its own
+    # descriptor (same process: raw pointers), runs on peer stores, switches back to RCCL and forth again mid-run
+    lbm_amd.set_default("transport", "auto")
+    with lbm_amd.LBM(p, ob, rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) as sim:
+        assert sim.get_option("transport") == 1
+        info = sim.peer_info()
+        sim.connect_peers(info, info)
+        assert sim.get_option("transport") == 3
         sim.upload(cells0)
-        sim.run(nsteps)
-        got, av = sim.download()   # rank mode: av_vels go through ncclAllReduce
-        re = sim.reynolds()
-    assert np.array_equal(got, ref), "state differs (transport %s, fuse %d, multistep %d)" % (transport, fuse, ms)
-    assert np.max(np.abs(av - av_ref) / av_ref) < 2e-6
-    assert abs(re / re_ref - 1) < 1e-5
+        sim.run(7)
+        sim.set_option("transport", 1)
+        sim.run(9)
+        sim.set_option("transport", 3)
+        sim.run(nsteps - 16)
+        got, av = sim.download()
+    assert np.array_equal(got, ref) and np.max(np.abs(av - av_ref) / av_ref) < 2e-6
 print("self-ring ok:", transport)

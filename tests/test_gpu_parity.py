@@ -292,23 +292,44 @@ def test_row_slabs_equal_single_slab(lbm, nslabs, ny, mode):
     assert max_rel(av_many, av_one) < 2e-6           # only the summation order of av_vels differs
 
 
-@pytest.mark.parametrize("transport", ["copy", "rccl"])
-def test_rccl_transport_self_ring(transport):
-    """the halo-exchange machinery with ONE slab that is its own ring neighbour; with transport=rccl every
+@pytest.mark.parametrize("transport", ["copy", "rccl", "peer"])
+def test_transport_self_ring(transport):
+    """the halo-exchange machinery with ONE slab that is its own ring neighbour, once per transport: rccl = every
     exchange is ncclSend/ncclRecv (to self) on a communicator made by ncclCommInitRank and av_vels go through
-    ncclAllReduce — the code path of the one-process-per-GPU launch, exercised on a single GPU"""
+    ncclAllReduce — the code path of the one-process-per-GPU launch; peer = halo_push kernel + flag words with both
+    consumer-side waits, and a context that switches between RCCL and peer stores mid-run"""
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_self_ring.py"), transport],
-                       capture_output=True, text=True, timeout=240)
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "self-ring ok" in r.stdout
 
 
+@pytest.mark.parametrize("world,nx,ny,nsteps,fuse,multistep,sync", [(2, 512, 96, 23, 3, 0, 0), (3, 256, 150, 29, 0, 8, 0),
+                                                                   (4, 2048, 64, 14, 4, 0, 1), (2, 256, 24, 11, 0, 0, 1)])
+def test_peer_transport_between_processes(world, nx, ny, nsteps, fuse, multistep, sync):
+    """the peer transport across PROCESS boundaries: `world` processes share the one GPU, each owns a row slab, maps
+    its neighbours' grids and flag words through HIP IPC, pushes its edge rows into them and waits on its own flags
+    (kernel spin or hipStreamWaitValue32); descriptors travel over torch.distributed/gloo.  The assembled state must
+    equal the single-slab run bit for bit.  (RCCL cannot do this on one GPU: it refuses two ranks per device.)"""
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_ipc_ring.py"),
+                        str(nx), str(ny), str(nsteps), str(fuse), str(multistep), str(sync)],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "ipc-ring ok" in r.stdout
+
+
 @pytest.mark.parametrize("nslabs,ny", [(2, 50), (3, 50), (2, 16), (4, 67), (5, 128), (2, 260)])
-def test_row_slabs_four_steps_per_launch(lbm, nslabs, ny, monkeypatch):
-    """slabs with halo depth 4 (what slabs of 8M cells and more get) and d2q9_step4 on edge + interior launches:
+def test_row_slabs_four_steps_per_launch(lbm, nslabs, ny, halo_defaults):
+    """slabs with halo depth 4 (what slabs of 2M cells and more get) and d2q9_step4 on edge + interior launches:
     bit-identical to one slab; 37 steps = nine full launch sets + one leftover step"""
-    monkeypatch.setenv("LBM_HALO_DEPTH", "4")
+    halo_defaults(halo_depth=4)
     rng = np.random.default_rng(6)
     nx, nsteps = 256, 37
     ob, cells0 = random_case(rng, nx, ny)
@@ -405,6 +426,59 @@ def test_full_run_passes_reference_checker(lbm, tmp_path, size):
     ref_re = {"128x128": 9.763598020526, "128x256": 37.18483826704, "256x256": 10.07703420252,
               "1024x1024": 3.377417654904}[size]
     assert abs(re / ref_re - 1.0) < 5e-3
+
+
+@pytest.mark.parametrize("mode", ["slabs8", "slabs8_copy", "ring_rccl", "ring_peer"])
+def test_partitioned_full_run_passes_checker(tmp_path, mode):
+    """BASELINE config 4 as far as one GPU goes: the shipped 1024x1024 input, all 20000 steps, row-partitioned — over
+    8 slabs (128 rows each, halo depth 8, d2q9_multi; peer stores or device-to-device copies) and as ONE rank that is
+    its own ring neighbour over RCCL send/recv and over peer stores — through the reference's checker against the
+    golden av_vels and the fp64-oracle final state, and bit-identical to the undivided run"""
+    import sys
+    from check.check import run_check
+    outs = {}
+    for m in ("single", mode):
+        d = tmp_path / m
+        d.mkdir()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_partitioned_run.py"), m, "1024x1024", str(d)],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "partitioned run ok" in r.stdout, r.stdout + r.stderr
+        outs[m] = np.load(d / "state.npz")
+    ref_av = golden_path("1024x1024.av_vels.dat", tmp_path)
+    ref_fs = generated_final_state("1024x1024", str(tmp_path / "ref_final_state.dat"))
+    out = io.StringIO()
+    code, avd, fsd = run_check(ref_av, ref_fs, str(tmp_path / mode / "av_vels.dat"), str(tmp_path / mode / "final_state.dat"), 1.0, out)
+    assert code == 0, out.getvalue()
+    assert abs(avd["max_diff_pcnt"]) < 0.5 and abs(fsd["max_diff_pcnt"]) < 0.5
+    one, many = outs["single"], outs[mode]
+    for k in ("ux", "uy", "u", "pr"):
+        assert np.array_equal(one[k], many[k]), k           # same per-cell arithmetic: identical final state
+    assert max_rel(many["av"], one["av"]) < 2e-6            # velocity sums: summation order only
+    assert abs(float(many["re"]) / float(one["re"]) - 1.0) < 1e-5
+
+
+def test_8192x8192_cavity_over_8_slabs_equals_one_slab(lbm):
+    """BASELINE config 5's grid, row-partitioned the way an 8-GPU run partitions it (8 slabs of 8192x1024 = 8M cells:
+    halo depth 4, d2q9_step4 on edge and interior launches, peer stores), all on the one GPU: 14 timesteps (three full
+    launch sets + a two-step remainder) bit-identical to the undivided grid"""
+    nx = ny = 8192
+    ob = np.zeros((ny, nx), dtype=np.int32)
+    ob[0, :] = ob[-1, :] = 1
+    ob[:, 0] = ob[:, -1] = 1
+    nsteps = 14
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    with lbm.LBM(p, ob) as sim:
+        sim.upload(None)
+        sim.run(nsteps)
+        one, av_one = sim.download()
+    with lbm.LBM(p, ob, devices=[0] * 8) as sim:
+        assert sim.get_option("nslabs") == 8 and sim.get_option("fuse") == 4 and sim.get_option("halo_depth") == 4
+        assert sim.get_option("transport") == 3
+        sim.upload(None)
+        sim.run(nsteps)
+        many, av_many = sim.download()
+    assert np.array_equal(one, many)
+    assert max_rel(av_many, av_one) < 2e-6
 
 
 def test_c_host_end_to_end(tmp_path):
@@ -539,7 +613,7 @@ def test_bench_one_process_per_gpu_path_single_rank():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, LBM_BENCH_RANK_MODE="1", LBM_FORCE_HALO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, LBM_BENCH_RANK_MODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "1", "--steps", "60", "--warmup", "12", "--nx", "2048", "--ny", "1024", "--no-extra",
