@@ -36,8 +36,21 @@ check/%.dat: tests/golden/check/%.dat.gz
 check: $(REF_AV_VELS_FILE) $(REF_FINAL_STATE_FILE)
 	python check/check.py --ref-av-vels-file=$(REF_AV_VELS_FILE) --ref-final-state-file=$(REF_FINAL_STATE_FILE) --av-vels-file=$(AV_VELS_FILE) --final-state-file=$(FINAL_STATE_FILE)
 
+# Sanitizer builds of everything that runs on the CPU (the reference had only a dead -DDEBUG target,
+# Makefile_old:30-31).  The C host is linked against a stand-in for the HIP library (tests/cpu/lbm_stub.c: the ABI of
+# include/lbm.h without numerics) so that its parsers and writers run under AddressSanitizer + UBSan on a CPU-only box;
+# the oracle's serial drivers get the same flags.  tests/test_host_cli.py and tests/test_sanitizers.py run them.
+SAN = -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1
+asan: $(EXE)-asan oracle-asan
+
+$(EXE)-asan: $(PKG)/host/d2q9-bgk.c tests/cpu/lbm_stub.c include/lbm.h
+	$(CC) -std=c99 $(SAN) -Wall -Wextra -D_GNU_SOURCE -Iinclude $(PKG)/host/d2q9-bgk.c tests/cpu/lbm_stub.c -o $@ -lm -lpthread
+
+oracle-asan:
+	$(MAKE) -C oracle asan
+
 clean:
-	rm -f $(LIB) $(EXE) $(EXE).exe
+	rm -f $(LIB) $(EXE) $(EXE).exe $(EXE)-asan
 	$(MAKE) -C oracle clean
 
-.PHONY: all check clean oracle
+.PHONY: all check clean oracle asan oracle-asan

@@ -4,20 +4,27 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one lattice-Boltzmann timestep (accelerate_flow + stream + collide + av_vels
-reduction, the reference's loop body d2q9-bgk.c:221-238) over the whole grid.  Workload: the
-synthetic 8192x8192 lid-driven cavity of BASELINE.json (only the four border lines blocked),
-uniform rest initial state, fp32.  With N > 1 the grid is row-partitioned over N ranks (one
-process per GPU), halos go by RCCL send/recv inside liblbm_hip.so, the velocity sums by an RCCL
-all-reduce; the RCCL id is distributed with torch.distributed.  Prints ONE JSON line on rank 0.
+A "step" is one lattice-Boltzmann timestep (accelerate_flow + stream + collide + av_vels reduction, the reference's
+loop body d2q9-bgk.c:221-238) over the whole grid.  Workload: the synthetic 8192x8192 lid-driven cavity of
+BASELINE.json (only the four border lines blocked), uniform rest initial state, fp32.  With N > 1 the grid is
+row-partitioned over N ranks (one process per GPU); the halo rows move inside liblbm_hip.so — by peer stores over
+xGMI into the neighbours' HIP-IPC-mapped grids and by RCCL send/recv, both measured back to back, the faster one is
+`value` — and the velocity sums by an RCCL all-reduce; the RCCL id and the peer descriptors are distributed with
+torch.distributed.  Prints ONE JSON line on rank 0.
 
-Algorithmic traffic: 72 B per lattice update (9 fp32 loads + 9 fp32 stores, kernels.cl:104-112,
-189-197); one launch of the step kernel updates every cell of the rank's slab once.
+What the roofline object means (every field is recomputable from the others and from profiles/):
+  a launch of the dominant kernel advances S timesteps and must read the grid once and write it once, whatever S is:
+  model bytes per launch = (72 + 1) B x cells (9 fp32 in, 9 fp32 out, one mask byte)         -> achieved, frac (<= 1)
+  algorithmic bytes      = 72 B per lattice update x S x cells (kernels.cl:104-112,189-197)
+                           -> roofline.algorithmic, can exceed the HBM peak: temporal blocking moves 1/S of them
+  traffic                = HBM bytes per launch counted by rocprofv3 (profiles/traffic.json: another run, named there)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,8 +32,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_PER_LU = 72.0
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_LU = 72.0       # algorithmic: 9 fp32 loads + 9 fp32 stores per lattice update
+MASK_BYTES = 1.0          # obstacle mask, one byte per cell and launch
+HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNELS = {0: "d2q9_step", 2: "d2q9_step2 (two timesteps per launch)", 3: "d2q9_step3 (three timesteps per launch)",
+           4: "d2q9_step4 (four timesteps per launch)"}
 
 
 def cavity(nx, ny):
@@ -36,31 +46,46 @@ def cavity(nx, ny):
     return ob
 
 
+def shipped(size):
+    import lbm_amd
+    return lbm_amd.read_inputs(os.path.join(ROOT, "inputs", "input_%s.params" % size),
+                               os.path.join(ROOT, "inputs", "obstacles_%s.dat" % size))
+
+
 def make_workload(name, nx, ny):
     if name == "cavity":
         return cavity(nx, ny)
     if name == "empty":
         return np.zeros((ny, nx), dtype=np.int32)
     if name == "tiled":
-        import lbm_amd
-        _, ob = lbm_amd.read_inputs(os.path.join(ROOT, "inputs", "input_1024x1024.params"),
-                                    os.path.join(ROOT, "inputs", "obstacles_1024x1024.dat"))
+        _, ob = shipped("1024x1024")
         assert nx % 1024 == 0 and ny % 1024 == 0
         return np.tile(ob, (ny // 1024, nx // 1024))
     raise ValueError(name)
 
 
-def cpu_baseline(nx, ny, obstacles, accel, budget_s=15.0):
-    """Serial fp32 oracle (the CPU restatement of the reference's timestep) on the host cores of
-    this box: a bounded number of timesteps of the same grid, 1 thread."""
+# ---- CPU baseline: the oracle (CPU restatement of the reference's timestep) on this box's host cores ----------
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def oracle_rate(precision, nx, ny, obstacles, accel, budget_s, max_steps, omp=False):
+    """(steps, seconds) of one oracle build on an nx x ny grid: at least 2 steps, at most max_steps / budget_s"""
     from oracle.oracle import Oracle
-    orc = Oracle("f32")
+    orc = Oracle(precision, omp=omp)
     p = orc.make_params(nx, ny, 1, 10, 0.1, accel, 1.85)
     orc.set_obstacles(p, obstacles)
     src = orc.init_cells(p)
     dst = np.empty_like(src)
-    # one untimed step for page faults, then as many as fit the budget (at least 2)
-    orc.accelerate_flow(p, src, obstacles)
+    orc.accelerate_flow(p, src, obstacles)   # one untimed step for page faults
     orc.timestep(p, src, dst, obstacles)
     src, dst = dst, src
     n, t0 = 0, time.perf_counter()
@@ -70,38 +95,64 @@ def cpu_baseline(nx, ny, obstacles, accel, budget_s=15.0):
         src, dst = dst, src
         n += 1
         el = time.perf_counter() - t0
-        if n >= 2 and (el > budget_s or n >= 64):
+        if n >= 2 and (el > budget_s or n >= max_steps):
             break
-    model = "unknown CPU"
+    return n, el
+
+
+def cpu_baseline(nx, ny, obstacles, accel):
+    """Serial fp32 oracle, 1 thread, on a bounded sample of the headline workload (`value`), plus the other figures
+    SURVEY.md 8(d) asks for: the 128x128 input run to the end and sent through the checker (BASELINE config 1), the
+    rate on the 1024x1024 input (200 steps) in fp32 and fp64, and an OpenMP figure over this process's CPU share.
+    About 35 s of CPU work in all."""
+    model, ncpu = cpu_model(), os.cpu_count()
+    n, el = oracle_rate("f32", nx, ny, obstacles, accel, 9.0, 64)
+    out = {"value": round(nx * ny * n / el / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "port",
+           "sample": "%d timesteps of the same %dx%d grid with the serial fp32 oracle (oracle/d2q9_oracle.c, gcc -O3 "
+                     "-march=native, 1 of %d host cores, %s)" % (n, nx, ny, ncpu, model)}
+    # BASELINE config 1: input_128x128 on the serial CPU path, full length, check.py must pass
     try:
-        with open("/proc/cpuinfo") as f:
-            for ln in f:
-                if ln.startswith("model name"):
-                    model = ln.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    # the same oracle with OpenMP over this process's CPU share, as a second reference point (a few steps only)
-    omp = None
+        import gzip
+        import io
+        import shutil
+        from check.check import run_check
+        with tempfile.TemporaryDirectory() as d:
+            files = [os.path.join(ROOT, "inputs", f) for f in ("input_128x128.params", "obstacles_128x128.dat")]
+            t0 = time.perf_counter()
+            r = subprocess.run([os.path.join(ROOT, "oracle", "d2q9-bgk-serial-f32")] + files, cwd=d, capture_output=True,
+                               text=True, timeout=120)
+            wall = time.perf_counter() - t0
+            el128 = float([ln for ln in r.stdout.splitlines() if ln.startswith("Elapsed time:")][0].split()[2])
+            refs = []
+            for name in ("128x128.av_vels.dat", "128x128.final_state.dat"):
+                dst = os.path.join(d, "ref_" + name)
+                with gzip.open(os.path.join(ROOT, "tests", "golden", "check", name + ".gz"), "rb") as fi, open(dst, "wb") as fo:
+                    shutil.copyfileobj(fi, fo)
+                refs.append(dst)
+            code, avd, fsd = run_check(refs[0], refs[1], os.path.join(d, "av_vels.dat"), os.path.join(d, "final_state.dat"),
+                                       1.0, io.StringIO())
+        out["input_128x128_full_run"] = {
+            "value": round(128 * 128 * 40000 / el128 / 1e6, 2), "unit": "MLUPS", "steps": 40000, "elapsed_s": round(el128, 3),
+            "wall_s_with_file_output": round(wall, 2), "precision": "f32", "check_py": "passed" if code == 0 else "FAILED",
+            "max_diff_pcnt": {"av_vels": round(abs(avd["max_diff_pcnt"]), 4), "final_state": round(abs(fsd["max_diff_pcnt"]), 4)}}
+    except Exception as e:  # the baseline is informational; never fail the bench over it
+        out["input_128x128_full_run"] = {"error": str(e)[:200]}
+    try:
+        _, ob1 = shipped("1024x1024")
+        n32, e32 = oracle_rate("f32", 1024, 1024, ob1, 0.01, 60.0, 200)
+        n64, e64 = oracle_rate("f64", 1024, 1024, ob1, 0.01, 60.0, 200)
+        out["input_1024x1024_rate"] = {"f32": {"value": round(1024 * 1024 * n32 / e32 / 1e6, 2), "steps": n32},
+                                       "f64": {"value": round(1024 * 1024 * n64 / e64 / 1e6, 2), "steps": n64}, "unit": "MLUPS", "cores": 1}
+    except Exception as e:
+        out["input_1024x1024_rate"] = {"error": str(e)[:200]}
     try:
         threads = max(1, min(16, len(os.sched_getaffinity(0))))
         os.environ["OMP_NUM_THREADS"] = str(threads)
-        orc_omp = Oracle("f32", omp=True)
-        p_omp = orc_omp.make_params(nx, ny, 1, 10, 0.1, accel, 1.85)
-        orc_omp.set_obstacles(p_omp, obstacles)
-        orc_omp.timestep(p_omp, src, dst, obstacles)
-        m, t1 = 0, time.perf_counter()
-        while m < 2 or (time.perf_counter() - t1 < 4.0 and m < 64):
-            orc_omp.accelerate_flow(p_omp, src, obstacles)
-            orc_omp.timestep(p_omp, src, dst, obstacles)
-            src, dst = dst, src
-            m += 1
-        omp = {"value": round(nx * ny * m / (time.perf_counter() - t1) / 1e6, 1), "cores": threads, "steps": m}
-    except Exception:  # the baseline is informational; never fail the bench over it
-        omp = None
-    return {"value": round(nx * ny * n / el / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "port", "openmp": omp,
-            "sample": "%d timesteps of the same %dx%d grid with the serial fp32 oracle "
-                      "(oracle/d2q9_oracle.c, gcc -O3 -march=native, 1 of %d host cores, %s)" % (n, nx, ny, os.cpu_count(), model)}
+        m, em = oracle_rate("f32", nx, ny, obstacles, accel, 4.0, 64, omp=True)
+        out["openmp"] = {"value": round(nx * ny * m / em / 1e6, 1), "cores": threads, "steps": m, "unit": "MLUPS"}
+    except Exception:
+        out["openmp"] = None
+    return out
 
 
 # ---- torch.distributed plumbing (also exercised with the gloo backend on CPU: tests/test_multirank_gloo.py) ----
@@ -126,11 +177,81 @@ def share_comm_id(dist, rank, blob, nbytes, device):
     return bytes(buf.cpu().numpy().tobytes())
 
 
+def gather_blobs(dist, blob, world, device):
+    """all_gather of one equally sized byte blob per rank (peer descriptors; per-rank statistics as padded JSON)"""
+    import torch
+    mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return [bytes(p.cpu().numpy().tobytes()) for p in parts]
+
+
 def max_over_ranks(dist, values, device):
     import torch
     t = torch.tensor(values, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t]
+
+
+def min_over_ranks(dist, value, device):
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t[0])
+
+
+class RankSim:
+    """One rank's slab of a row-partitioned grid and the halo transports it can use."""
+
+    def __init__(self, lbm_amd, dist, rank, world, local_rank, params, obstacles, want, device):
+        cid = share_comm_id(dist, rank, lbm_amd.comm_id() if rank == 0 else None, lbm_amd.load_library().lbm_comm_id_size(), device)
+        self.sim = lbm_amd.LBM(params, obstacles, rank=rank, nranks=world, device=local_rank, comm=cid)
+        self.transports = ["rccl"]
+        self.peer_error = None
+        if want in ("peer", "both"):
+            # every rank maps its ring neighbours' grids through HIP IPC; the ring uses them only if ALL ranks could
+            ok = 1.0
+            try:
+                infos = gather_blobs(dist, self.sim.peer_info(), world, device)
+                self.sim.connect_peers(infos[(rank - 1) % world], infos[(rank + 1) % world])
+            except lbm_amd.LBMError as e:
+                ok, self.peer_error = 0.0, str(e)
+            if min_over_ranks(dist, ok, device) > 0.5:
+                self.transports = ["peer"] if want == "peer" else ["peer", "rccl"]
+            elif self.sim.get_option("transport") == 3:
+                self.sim.set_option("transport", 1)
+
+    def use(self, name):
+        self.sim.set_option("transport", {"rccl": 1, "peer": 3}[name])
+
+
+def timed_run(sim, dist, device, torch, warmup, steps):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
+    def fence():
+        sim.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+    sim.run(warmup)
+    fence()
+    t0 = time.perf_counter()
+    loop_ms = sim.run_timed(steps)   # HIP events on the stream the step kernels run on
+    fence()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        wall, loop_ms = max_over_ranks(dist, [wall, loop_ms], device)
+    return wall, loop_ms
+
+
+def profile_all_ranks(sim, dist, rank, world, device, nsteps, extra):
+    """lbm_run_profiled on every rank, gathered on all: where a launch set's time goes (edge / exchange / interior)"""
+    st = sim.run_profiled(nsteps)
+    st = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()}
+    st.update(rank=rank, **extra)
+    if st.get("peer_error"):
+        st["peer_error"] = st["peer_error"][:160]
+    blob = json.dumps(st).encode().ljust(1024)[:1024]
+    return [json.loads(b.decode().strip()) for b in gather_blobs(dist, blob, world, device)]
 
 
 def main():
@@ -145,8 +266,10 @@ def main():
                     help="strong: the nx x ny grid is split over the ranks; weak: every rank gets ny rows")
     ap.add_argument("--accel", type=float, default=0.005)
     ap.add_argument("--fuse", type=int, default=-1, help="timesteps per launch of the register/LDS-window kernels: 0, 1 (= 2), 3, 4; -1: library default")
+    ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl"],
+                    help="N > 1: halo transport(s) to measure; the faster one is `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 1024x1024 side measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 1024x1024 and reference-rule side measurements")
     args = ap.parse_args()
 
     import torch  # device plumbing + torch.distributed (RCCL) only
@@ -164,45 +287,48 @@ def main():
     # one GPU per rank; if the launcher narrowed the visible devices per rank, index within what is visible
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     # LBM_BENCH_RANK_MODE=1 drives the one-process-per-GPU code path with a single rank: the rank is its own ring
     # neighbour (default "force_halo"), so torch.distributed + the library's RCCL communicator run on a one-GPU box
     rank_mode = world > 1 or os.environ.get("LBM_BENCH_RANK_MODE") == "1"
     if rank_mode and world == 1:
         lbm_amd.set_default("force_halo", 1)
-    dist = init_dist("nccl", rank, world, torch.device("cuda", local_rank)) if rank_mode else None
+    dist = init_dist("nccl", rank, world, device) if rank_mode else None
 
     nx = args.nx
     ny = args.ny * (world if args.scaling == "weak" else 1)
-    total_steps = args.warmup + args.steps
+    total_steps = (2 if rank_mode else 1) * (args.warmup + args.steps) + 256
     obstacles = make_workload(args.workload, nx, ny)
     params = lbm_amd.make_params(nx, ny, total_steps, 10, 0.1, args.accel, 1.85, obstacles)
 
+    rs = None
     if rank_mode:
-        cid = share_comm_id(dist, rank, lbm_amd.comm_id() if rank == 0 else None,
-                            lbm_amd.load_library().lbm_comm_id_size(), torch.device("cuda", local_rank))
-        sim = lbm_amd.LBM(params, obstacles, rank=rank, nranks=world, device=local_rank, comm=cid)
+        rs = RankSim(lbm_amd, dist, rank, world, local_rank, params, obstacles, args.transport, device)
+        sim, transports = rs.sim, rs.transports
     else:
-        sim = lbm_amd.LBM(params, obstacles)
+        sim, transports = lbm_amd.LBM(params, obstacles), [None]
     if args.fuse >= 0:
         sim.set_option("fuse", args.fuse)
     fused = {0: 0, 1: 2, 3: 3, 4: 4}[sim.get_option("fuse")]   # timesteps per launch of the dominant kernel (0: one)
+    multistep = sim.get_option("multistep")
     sim.upload(None)  # uniform rest state, built on the device
     y0, y1 = sim.row_range()
 
-    def fence():
-        sim.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    sim.run(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    loop_ms = sim.run_timed(args.steps)   # HIP events on the stream the step kernels run on
-    fence()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        wall, loop_ms = max_over_ranks(dist, [wall, loop_ms], torch.device("cuda", local_rank))
+    # ---- the timed region(s): one per halo transport, the faster one is reported as `value` -----------------------
+    runs = {}
+    for tr in transports:
+        if tr:
+            rs.use(tr)
+        wall, loop_ms = timed_run(sim, dist, device, torch, args.warmup, args.steps)
+        runs[tr or "single"] = {"wall_s": wall, "loop_ms": loop_ms}
+    best = min(runs, key=lambda k: runs[k]["wall_s"])
+    wall, loop_ms = runs[best]["wall_s"], runs[best]["loop_ms"]
+    # where a launch set's time goes on every rank (timing events; a separate short run, outside the timed region)
+    per_rank = None
+    if rank_mode:
+        rs.use(best)
+        per_rank = profile_all_ranks(sim, dist, rank, world, device, 8 * max(multistep, fused, 1),
+                                     dict(rows=y1 - y0, rccl_world=world, transports_available=transports, peer_error=rs.peer_error))
 
     # sanity on the result of the timed run: finite, positive average velocity on every rank
     _, av = sim.download(cells=False)
@@ -213,11 +339,13 @@ def main():
         lups = nx * ny * args.steps / wall
         rows_local = y1 - y0
         # the dominant kernel advances `steps_per_launch` timesteps of the rank's slab per launch
-        steps_per_launch = fused if fused else 1
+        steps_per_launch = multistep if multistep else (fused if fused else 1)
         launches = args.steps // steps_per_launch + args.steps % steps_per_launch
         launch_s = loop_ms * 1e-3 / launches
-        alg_bytes = BYTES_PER_LU * nx * rows_local * steps_per_launch
-        achieved = alg_bytes / launch_s / 1e9
+        cells_local = nx * rows_local
+        model_bytes = (BYTES_PER_LU + MASK_BYTES) * cells_local
+        achieved = model_bytes / launch_s / 1e9
+        alg_gbps = BYTES_PER_LU * cells_local * steps_per_launch / launch_s / 1e9
         out = {
             "metric": "MLUPS", "value": round(lups / 1e6, 1), "unit": "MLUPS (million lattice updates/s)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -228,41 +356,79 @@ def main():
                 "tiled": "obstacles_1024x1024 tiled up"}[args.workload]),
                 "nx": nx, "ny": ny, "rows_per_gpu": rows_local, "partition": "rows x%d" % world,
                 "omega": 1.85, "accel": args.accel, "density": 0.1},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": {0: "d2q9_step", 2: "d2q9_step2 (two timesteps per launch)",
-                                    3: "d2q9_step3 (three timesteps per launch)",
-                                    4: "d2q9_step4 (four timesteps per launch)"}[fused],
-                         "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": steps_per_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": ("d2q9_multi (%d timesteps per launch on LDS tiles)" % multistep) if multistep else KERNELS[fused],
+                "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": steps_per_launch,
+                "model_bytes_per_launch": model_bytes,
+                "formula": "achieved = model_bytes_per_launch / launch_us; model_bytes_per_launch = (72 + 1) B x %d cells of the "
+                           "rank's slab: a launch reads the grid once, writes it once and reads the byte mask, however many "
+                           "timesteps it advances; launch_us = HIP-event time of the step loop / launches" % cells_local,
+                "algorithmic": {"bytes_per_lattice_update": BYTES_PER_LU, "gbps": round(alg_gbps, 1),
+                                "frac_of_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
+                                "formula": "72 B x cells x steps_per_launch / launch_us (SURVEY.md 8d); above the 8 TB/s peak where "
+                                           "temporal blocking keeps steps_per_launch-1 intermediate states on the chip: the "
+                                           "speed-up over a perfect one-step-per-launch kernel, not a bandwidth"}},
             "result_ok": ok,
         }
         # measured PMC traffic of the same command, when a profile of this workload is committed
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1:
+        if os.path.exists(tp) and world == 1 and not multistep:
             with open(tp) as f:
                 tj = json.load(f)
             key = "%dx%d/step%d" % (nx, ny, steps_per_launch)
             if key in tj:
-                out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_frac"] = round(tj[key]["hbm_bytes_per_launch"] / launch_s / 1e9 / HBM_PEAK_GBPS, 4)
-                out["roofline"]["traffic_source"] = tj[key].get("source")
+                tb = tj[key]["hbm_bytes_per_launch"]
+                rf = out["roofline"]
+                rf["traffic"] = tb
+                rf["traffic_measured_in_run"] = False
+                rf["traffic_source"] = tj[key].get("source")
+                rf["traffic_frac"] = round(tb / launch_s / 1e9 / HBM_PEAK_GBPS, 4)
+                rf["traffic_over_model"] = round(tb / model_bytes, 4)
+                if tj[key].get("evidence"):
+                    rf["bound_evidence"] = tj[key]["evidence"]
         # what a plain float4 copy achieves on this box right now (context for `frac`; the spec peak stays `peak`)
         try:
             out["roofline"]["copy_kernel_gbps"] = round(lbm_amd.copy_bandwidth_gbps(1 << 30, 10), 1)
+            out["roofline"]["frac_of_copy_kernel"] = round(achieved / out["roofline"]["copy_kernel_gbps"], 4)
         except lbm_amd.LBMError:
             pass
-        if fused:
-            out["roofline"]["note"] = ("frac uses the ALGORITHMIC 72 B per lattice update; the multi-step kernels keep the "
-                                       "intermediate states in registers and really move far fewer bytes per update (traffic), "
-                                       "so frac can exceed 1 while traffic_frac is the share of the 8 TB/s peak actually used")
+        if rank_mode:
+            out["transports"] = {k: {"value": round(nx * ny * args.steps / v["wall_s"] / 1e6, 1),
+                                     "ms_per_step": round(v["wall_s"] * 1e3 / args.steps, 5)} for k, v in runs.items()}
+            out["transport"] = best
+            out["rccl_world_size"] = world
+            out["per_rank_launch_set_us"] = per_rank
     sim.close()
 
-    if world == 1 and rank == 0:
-        if not args.no_extra and (nx, ny) != (1024, 1024):
+    extra = not args.no_extra and (nx, ny) != (1024, 1024)
+    if extra and rank_mode:
+        # the 1024x1024 input of the reference row-partitioned over the same ranks (BASELINE config 4: strong scaling)
+        p2, ob2 = shipped("1024x1024")
+        n2, w2 = 4000, 400
+        p2.max_iters = 2 * (n2 + w2) + 256
+        rs2 = RankSim(lbm_amd, dist, rank, world, local_rank, p2, ob2, args.transport, device)
+        rs2.sim.upload(None)
+        res2 = {}
+        for tr in rs2.transports:
+            rs2.use(tr)
+            res2[tr], _ = timed_run(rs2.sim, dist, device, torch, w2, n2)
+        b2 = min(res2, key=res2.get)
+        rs2.use(b2)
+        pr2 = profile_all_ranks(rs2.sim, dist, rank, world, device, 8 * max(rs2.sim.get_option("multistep"), 3), {})
+        if rank == 0:
+            out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat, rows x%d (strong scaling of the reference's "
+                                       "largest input)" % world,
+                           "value": round(1024 * 1024 * n2 / res2[b2] / 1e6, 1), "unit": "MLUPS", "steps": n2, "warmup": w2, "transport": b2,
+                           "transports": {k: round(1024 * 1024 * n2 / v / 1e6, 1) for k, v in res2.items()},
+                           "us_per_step": round(res2[b2] / n2 * 1e6, 3), "halo_depth": rs2.sim.get_option("halo_depth"),
+                           "per_rank_launch_set_us": pr2}
+        rs2.sim.close()
+    if world == 1 and rank == 0 and not rank_mode:
+        if extra:
             # the reference's own largest input, for the 1024x1024 figure the north star asks for
-            p2, ob2 = lbm_amd.read_inputs(os.path.join(ROOT, "inputs", "input_1024x1024.params"),
-                                          os.path.join(ROOT, "inputs", "obstacles_1024x1024.dat"))
+            p2, ob2 = shipped("1024x1024")
             n2 = 4000
             p2.max_iters = n2 + 200
             with lbm_amd.LBM(p2, ob2) as s2:
@@ -273,9 +439,40 @@ def main():
                 ms2 = s2.run_timed(n2)
                 s2.sync()
                 w2 = time.perf_counter() - t1
-            out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat (fits the 256 MiB Infinity Cache)",
-                           "value": round(1024 * 1024 * n2 / w2 / 1e6, 1), "unit": "MLUPS", "steps": n2,
-                           "roofline_frac_if_hbm": round(BYTES_PER_LU * 1024 * 1024 / (ms2 * 1e-3 / n2) / 1e9 / HBM_PEAK_GBPS, 4)}
+                f2 = {0: 1, 1: 2, 3: 3, 4: 4}[s2.get_option("fuse")]
+            out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat (both grids fit the 256 MiB Infinity Cache: "
+                                       "these bytes come from cache, not HBM — profiles/r02_config3.txt)",
+                           "value": round(1024 * 1024 * n2 / w2 / 1e6, 1), "unit": "MLUPS", "steps": n2, "us_per_step": round(ms2 / n2 * 1e3, 3),
+                           "steps_per_launch": f2,
+                           "model_gbps": round((BYTES_PER_LU + MASK_BYTES) * 1024 * 1024 / (ms2 * 1e-3 / n2 * f2) / 1e9, 1),
+                           "algorithmic_gbps": round(BYTES_PER_LU * 1024 * 1024 / (ms2 * 1e-3 / n2) / 1e9, 1)}
+            # reference-rule figures (d2q9-bgk.c:196-263: initial state + step loop + read-back of av_vels and the state)
+            ref = {}
+            p3 = lbm_amd.make_params(nx, ny, args.steps, 10, 0.1, args.accel, 1.85, obstacles)
+            with lbm_amd.LBM(p3, obstacles) as s3:
+                t1 = time.perf_counter()
+                s3.upload(None)
+                s3.run(args.steps)
+                s3.sync()
+                s3.download(cells=False)
+                s3.final_state()
+                s3.reynolds()
+                tr = time.perf_counter() - t1
+            ref["headline_grid"] = {"value": round(nx * ny * args.steps / tr / 1e6, 1), "unit": "MLUPS", "steps": args.steps,
+                                    "elapsed_s": round(tr, 4),
+                                    "what": "device-side initial state + %d steps + av_vels + the four final_state columns "
+                                            "(%.2f GB to pageable host memory) + Reynolds number, wall clock" % (args.steps, 4 * nx * ny * 4 / 1e9)}
+            try:
+                with tempfile.TemporaryDirectory() as d:
+                    r = subprocess.run([os.path.join(ROOT, "d2q9-bgk.exe"), os.path.join(ROOT, "inputs", "input_1024x1024.params"),
+                                        os.path.join(ROOT, "inputs", "obstacles_1024x1024.dat")], cwd=d, capture_output=True, text=True,
+                                       timeout=300, env=dict(os.environ, LBM_NO_OUTPUT="1"))
+                el = float([ln for ln in r.stdout.splitlines() if ln.startswith("Elapsed time:")][0].split()[2])
+                ref["c_host_input_1024x1024"] = {"value": round(1024 * 1024 * 20000 / el / 1e6, 1), "unit": "MLUPS", "steps": 20000,
+                                                 "elapsed_s": el, "what": "./d2q9-bgk.exe on the shipped input: its 'Elapsed time' line"}
+            except Exception as e:
+                ref["c_host_input_1024x1024"] = {"error": str(e)[:200]}
+            out["reference_rule"] = ref
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, obstacles, args.accel)
     if rank == 0:

@@ -188,12 +188,18 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "chunk_min"    fewest rows per wave at the tapered end of the schedule (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)
  *   "nt_stores"    1 = non-temporal stores for the destination grid, 0 = plain, -1 = auto
- *   "nt_loads"     source loads of the multi-step kernels: 0 = plain, 1 = non-temporal, 2 = non-temporal except
- *                  for the rows shared with the neighbouring chunk, -1 = auto (2 for the two-step kernel, 0 for
- *                  the three-step kernel with its windows in LDS)
+ *   "nt_loads"     source loads of the two- and three-step kernels: 0 = plain, 1 = non-temporal, 2 = non-temporal
+ *                  except for the rows shared with the neighbouring chunk, -1 = auto (2 for the two-step kernel, 0 for
+ *                  the three-step kernel with its windows in LDS).  The four-step kernel always loads plain (it has no
+ *                  register to spare: its non-temporal forms spilled to scratch and were removed).
  *   "transport"    halo transport of a context that carries halo rows: 1 = RCCL send/recv (needs a communicator),
  *                  3 = peer stores (needs connected peers); read-only values 2 = device-to-device copies, 0 = none yet
- *   "halo_sync"    peer transport, consumer side: 0 = wait kernel with a bounded spin (default), 1 = hipStreamWaitValue32
+ *   "halo_sync"    peer transport, consumer side: 0 = wait kernel with a bounded spin (default), 1 = hipStreamWaitValue32,
+ *                  2 = the edge tiles of the consuming launch poll the flag words themselves (compact launch sets only,
+ *                  elsewhere like 0)
+ *   "compact"      peer transport + LDS-tile kernel (small slabs): -1/1 = one launch per launch set on one stream, the
+ *                  edge tiles store the halo rows into the neighbours themselves; 0 = edge launch / interior launch /
+ *                  push kernel on two streams like the larger slabs
  * Read-only through lbm_get_option: "nslabs", "fuse_units", "halo_depth".
  */
 int lbm_set_option(lbm_ctx *ctx, const char *key, long value);

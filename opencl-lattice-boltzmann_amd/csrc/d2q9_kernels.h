@@ -1295,19 +1295,7 @@ __global__ __launch_bounds__(kBlock) void halo_push(const PushArgs a) {
 // Consumer side: one wave, lanes 0 and 1 poll the two flag words until both have reached `seq`.  The spin is
 // BOUNDED (timeout in 100-MHz ticks of s_memrealtime): a neighbour that never arrives sets the error word, which
 // lbm_sync reports, instead of hanging the GPU.  The launch that follows starts with the usual kernel-start acquire.
-__global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
-  if (threadIdx.x < 2) {
-    const uint32_t *f = flags + threadIdx.x;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int32_t)(flag_load_system(f) - seq) < 0) {
-      __builtin_amdgcn_s_sleep(4);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
-        atomicOr(err, 1u);
-        break;
-      }
-    }
-  }
-}
+__global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout);
 
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------
 // Grids of a few hundred cells a side are bound by launch latency, not bandwidth (one step of 128x128 is
@@ -1334,22 +1322,65 @@ struct MultiArgs {
   int row_off;              // stored row of owned row 0; 0 = no halo rows: y wraps periodically inside the kernel
   int tiles_x;
   int ty_begin, ty_split, ty_begin2;  // tile row of workgroup-row t: t < ty_split ? ty_begin + t : ty_begin2 + (t - ty_split) ...
-  int ty_split2, ty_begin3;           // ... and ty_begin3 + (t - ty_split2) from t = ty_split2 on (0 = no third range)
+  int ty_split2, ty_begin3;           // ... and, PEER form only, ty_begin3 + (t - ty_split2) from t = ty_split2 on
   int T;                    // steps in this launch (<= row_off when there are halo rows)
   int gy_off, ny_global;    // stored row r holds global row (gy_off + r) mod ny_global; accelerate_flow acts on ny_global-2
   int accel_next;           // apply the following step's accelerate_flow to the final state
   float omega, aw1, aw2;
   // peer-halo transport, fused ("compact" launch sets of small slabs): the first edge_blocks workgroups hold the
-  // push_rows bottom and top owned rows; they store those rows a second time, write-through, into the ring neighbours'
-  // halo rows, and the last of them to finish raises the neighbours' flag words to seq.  push_rows == 0: off.
-  float *push_lo, *push_hi;     // the south neighbour's top halo rows / the north neighbour's bottom halo rows (plane 0, row 0)
-  uint32_t *flag_lo, *flag_hi;
-  unsigned *ticket;
-  uint32_t seq;
-  int push_rows, edge_blocks;
+  // bottom and top owned rows the ring neighbours need; they store those rows a second time, write-through, into the
+  // neighbours' halo rows, and the last of them to finish raises the neighbours' flag words to seq (peer_mode bit 0).
+  // Bit 1 (option halo_sync = 2): the same workgroups — the only ones whose regions reach into the halo rows — poll
+  // this slab's own flag words for wait_seq before they load (bounded, like halo_wait).  Everything that does not
+  // change from launch to launch sits in a device-resident MultiPeer: as kernel arguments those pointers stayed live in
+  // SGPRs to the end of the kernel, 92 instead of 76, which costs the 16x16 / 16x8 tiles their second workgroup per CU
+  // (more than 80 SGPRs admit 28 waves per CU, not 32: 384x384 4.54 instead of 3.46 us/step).
+  const struct MultiPeer *peer;
+  uint32_t seq, wait_seq;
+  int peer_mode, peer_buf, edge_blocks;   // peer_buf: index of the destination grid (which of the neighbours' two grids)
 };
 
-template <int kMultiTX, int kMultiTY>
+struct MultiPeer {
+  float *push_lo[2], *push_hi[2];  // per grid: the south neighbour's top halo rows / the north neighbour's bottom halo rows
+  uint32_t *flag_lo, *flag_hi;     // the neighbours' flag words for pushes arriving from this slab
+  unsigned *ticket;
+  const uint32_t *wait_flags;      // this slab's own flag words
+  uint32_t *wait_err;
+  unsigned long long wait_ticks;
+  int push_rows;
+};
+
+// The kernel's own argument block, re-read where it is used: fields needed only at the very start or the very end of
+// a long kernel otherwise sit in SGPRs all the way through (the asm hides that this is the preloaded argument copy).
+template <class Args>
+__device__ __forceinline__ const Args *late_args() {
+  unsigned long long p = (unsigned long long)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return reinterpret_cast<const Args *>(p);
+}
+
+// bounded spin of lanes 0 and 1 on the two flag words (see halo_wait)
+__device__ __forceinline__ void spin_on_flags(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+  if (threadIdx.x < 2) {
+    const uint32_t *f = flags + threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(flag_load_system(f) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
+        atomicOr(err, 1u);
+        break;
+      }
+    }
+  }
+}
+
+__global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+  spin_on_flags(flags, seq, err, timeout);
+}
+
+// PEER: the compact launch-set form (three tile-row ranges, fused wait and push); a separate instantiation so that the
+// plain form keeps its 76-78 SGPRs
+template <int kMultiTX, int kMultiTY, bool PEER = false>
 __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
   constexpr int kMultiRX = kMultiTX + 2 * kMultiMaxT, kMultiRY = kMultiTY + 2 * kMultiMaxT;
   __shared__ float lds[2][9][kMultiRY * kMultiRX];
@@ -1359,8 +1390,9 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
   const int T = a.T;
   const int RX = kMultiTX + 2 * T, RY = kMultiTY + 2 * T;
   const int trow = blockIdx.x / a.tiles_x, tile_x = blockIdx.x - trow * a.tiles_x;
-  const int tile_y = trow < a.ty_split ? a.ty_begin + trow
-                     : ((a.ty_split2 > 0 && trow >= a.ty_split2) ? a.ty_begin3 + (trow - a.ty_split2) : a.ty_begin2 + (trow - a.ty_split));
+  int tile_y = trow < a.ty_split ? a.ty_begin + trow : a.ty_begin2 + (trow - a.ty_split);
+  if constexpr (PEER)
+    if (trow >= a.ty_split2) tile_y = a.ty_begin3 + (trow - a.ty_split2);
   const int gx0 = tile_x * kMultiTX - T, oy0 = tile_y * kMultiTY - T;  // region cell (0,0): column, owned-row index
   const bool periodic = (a.row_off == 0);
   const size_t ps = a.plane_stride;
@@ -1376,6 +1408,18 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
     return r < 0 ? 0 : (r >= a.ext_rows ? a.ext_rows - 1 : r);  // clamped rows only feed cells that are never stored
   };
 
+  // In-kernel wait for the neighbours' halo rows (halo_sync = 2).  No acquire fence behind it: L1 and L2 were invalidated
+  // when this kernel started, the only loads of halo-row lines in this kernel are those of the edge tiles, and every
+  // one of them comes after the poll below has seen the flag — which the producer raised after its write-through
+  // stores had drained — so no cache can hold an older copy of those lines.
+  if constexpr (PEER) {
+    const MultiArgs *la = late_args<MultiArgs>();
+    if ((la->peer_mode & 2) && (int)blockIdx.x < la->edge_blocks) {
+      const MultiPeer *pp = la->peer;
+      spin_on_flags(pp->wait_flags, la->wait_seq, pp->wait_err, pp->wait_ticks);
+      __syncthreads();
+    }
+  }
   // region -> LDS (periodic wrap in x, kernels.cl:99-102)
   {
     const float inv = 1.0f / (float)RX;
@@ -1455,24 +1499,31 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
   // fused push (see MultiArgs): the edge tiles' share of the rows the ring neighbours need, 16 bytes per lane straight
   // from the LDS copy of the final state; a quad that hangs over the end of a row spills into the row padding
   // (plane_stride is a multiple of 64 floats >= nx: never read)
-  if (a.push_rows > 0 && (int)blockIdx.x < a.edge_blocks) {
-    const int fin = T & 1;
-    constexpr int Q = kMultiTX / 4;
-    const int top0 = a.rows - a.push_rows;  // first owned row that goes north
-    for (int i = tid; i < 9 * kMultiTY * Q; i += kMultiThreads) {
-      const int k = i / (kMultiTY * Q), r = i - k * (kMultiTY * Q);
-      const int oy = r / Q, q = r - oy * Q;
-      const int orow = tile_y * kMultiTY + oy, gx = tile_x * kMultiTX + 4 * q;
-      if (orow >= a.rows || gx >= a.nx) continue;
-      const bool lo = orow < a.push_rows, hi = orow >= top0;
-      if (!lo && !hi) continue;
-      const float *src = &lds[fin][k][(oy + T) * kMultiRX + 4 * q + T];
-      v4f v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-      if (lo) store4_through(a.push_lo + (size_t)orow * a.row_stride + k * ps + gx, v);
-      if (hi) store4_through(a.push_hi + (size_t)(orow - top0) * a.row_stride + k * ps + gx, v);
+  if constexpr (PEER) {
+    const MultiArgs *la = late_args<MultiArgs>();
+    const int edge_blocks = la->edge_blocks;
+    if ((la->peer_mode & 1) && (int)blockIdx.x < edge_blocks) {
+      const MultiPeer *pp = la->peer;
+      const int fin = T & 1;
+      constexpr int Q = kMultiTX / 4;
+      const int push_rows = pp->push_rows;
+      float *const push_lo = pp->push_lo[la->peer_buf], *const push_hi = pp->push_hi[la->peer_buf];
+      const int top0 = a.rows - push_rows;  // first owned row that goes north
+      for (int i = tid; i < 9 * kMultiTY * Q; i += kMultiThreads) {
+        const int k = i / (kMultiTY * Q), r = i - k * (kMultiTY * Q);
+        const int oy = r / Q, q = r - oy * Q;
+        const int orow = tile_y * kMultiTY + oy, gx = tile_x * kMultiTX + 4 * q;
+        if (orow >= a.rows || gx >= a.nx) continue;
+        const bool lo = orow < push_rows, hi = orow >= top0;
+        if (!lo && !hi) continue;
+        const float *src = &lds[fin][k][(oy + T) * kMultiRX + 4 * q + T];
+        v4f v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+        if (lo) store4_through(push_lo + (size_t)orow * a.row_stride + k * ps + gx, v);
+        if (hi) store4_through(push_hi + (size_t)(orow - top0) * a.row_stride + k * ps + gx, v);
+      }
+      drain_stores();
+      publish_when_last(pp->ticket, (unsigned)edge_blocks, pp->flag_lo, pp->flag_hi, la->seq);
     }
-    drain_stores();
-    publish_when_last(a.ticket, (unsigned)a.edge_blocks, a.flag_lo, a.flag_hi, a.seq);
   }
 }
 

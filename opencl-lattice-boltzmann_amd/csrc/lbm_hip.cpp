@@ -181,6 +181,7 @@ struct Slab {
   // [1] by the north neighbour, [2] error bits of halo_wait, [3] ticket of halo_push
   uint32_t *halo_flags = nullptr;
   PeerLink south, north;
+  lbm::MultiPeer *d_peer = nullptr;   // device copy of what the fused push / wait of d2q9_multi needs (filled when the ring is connected)
   double *av_tmp = nullptr;   // all-reduce target of the velocity record (rank mode), allocated on first use
   // output-stage scratch
   float *fin_partials = nullptr;
@@ -439,10 +440,20 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
   // tile size of d2q9_multi: the largest of 32x16, 16x16, 16x8 that still gives ~one tile per two CUs
   {
     static const int shapes[3][2] = {{32, 16}, {16, 16}, {16, 8}};
-    // measured (tools/ab_tiles.py, us/step at T = 8 for 32x16 / 16x16 / 16x8): 128x128 1.85 / 1.55 / 1.38,
-    // 128x256 1.94 / 1.63 / 1.49, 256x256 1.97 / 1.85 / 2.07, 384x384 3.86 / 3.46 / 4.25, 512x512 3.89 / 4.12 / 6.18
-    const long t32 = (long)div_up(c->p.nx, 32) * div_up(s.rows, 16);
-    int pick = t32 <= 64 ? 2 : (t32 <= 384 ? 1 : 0);
+    // A tile's cost is its cell updates over the T = 8 shrinking sub-steps (32x16: 7344, 16x16: 4400, 16x8: 2928) and
+    // a CU works through ceil(tiles / 256) of them, so take the shape with the least work per CU (ties: the larger
+    // tile, less redundant halo).  Matches every measurement (tools/ab.py --opts tile_shape=.., us/step for 32x16 /
+    // 16x16 / 16x8): 128x128 1.85 / 1.55 / 1.38, 128x256 1.94 / 1.63 / 1.49, 256x256 1.97 / 1.85 / 2.07, 384x384 3.86 /
+    // 3.46 / 4.25, 512x512 3.89 / 4.12 / 6.18 and the slabs of a ring (r02): 1024x128 2.51 / 3.41 / 5.25, 1024x256
+    // 3.97 / 5.95 / 9.66, 1024x512 7.13 / 11.15 / 18.65 (round 1 chose by tile count alone and gave those slabs 16x16)
+    static const long updates[3] = {7344, 4400, 2928};
+    int pick = 0;
+    long best = -1;
+    for (int k = 0; k < 3; k++) {
+      const long tiles = (long)div_up(c->p.nx, shapes[k][0]) * div_up(s.rows, shapes[k][1]);
+      const long work = (long)div_up(tiles, 256) * updates[k];
+      if (best < 0 || work < best) { best = work; pick = k; }
+    }
     if (c->tile_shape >= 0) pick = std::min(2, c->tile_shape);
     // slab mode: the edge tile rows must cover the halo depth
     if (multi && shapes[pick][1] < c->halo_depth) pick = 1;
@@ -658,21 +669,16 @@ void launch_step3(const lbm_ctx *c, const Step2Args &a0, float *partials3, int u
 
 void launch_step4(const lbm_ctx *c, const Step2Args &a0, float *partials3, float *partials4, int units, hipStream_t st,
                   bool paired = false) {
-  const int ntl = c->nt_loads >= 0 ? c->nt_loads : 0;
+  // source loads are always plain here: the kernel sits at the 256-VGPR limit and its non-temporal forms spill (6 and
+  // 8 registers to scratch) — option "nt_loads" applies to the two- and three-step kernels only (lbm_set_option)
+  (void)c;
   if (paired) {
     Step2Args a = a0;
     a.units_per_band = a0.units_per_band / 2;  // chunk pairs x strips
-    const dim3 grid(units / 2), block(128);
-    if (ntl == 2) hipLaunchKernelGGL((d2q9_step4p<true, 2>), grid, block, 0, st, a, partials3, partials4);
-    else if (ntl == 1) hipLaunchKernelGGL((d2q9_step4p<true, 1>), grid, block, 0, st, a, partials3, partials4);
-    else hipLaunchKernelGGL((d2q9_step4p<true, 0>), grid, block, 0, st, a, partials3, partials4);
+    hipLaunchKernelGGL((d2q9_step4p<true, 0>), dim3(units / 2), dim3(128), 0, st, a, partials3, partials4);
     return;
   }
-  const Step2Args &a = a0;
-  const dim3 grid(units), block(64);
-  if (ntl == 2) hipLaunchKernelGGL((d2q9_step4<true, 2>), grid, block, 0, st, a, partials3, partials4);
-  else if (ntl == 1) hipLaunchKernelGGL((d2q9_step4<true, 1>), grid, block, 0, st, a, partials3, partials4);
-  else hipLaunchKernelGGL((d2q9_step4<true, 0>), grid, block, 0, st, a, partials3, partials4);
+  hipLaunchKernelGGL((d2q9_step4<true, 0>), dim3(units), dim3(64), 0, st, a0, partials3, partials4);
 }
 
 MultiArgs base_args_multi(const lbm_ctx *c, const Slab &s, int src, int T, bool accel_next) {
@@ -698,8 +704,14 @@ MultiArgs base_args_multi(const lbm_ctx *c, const Slab &s, int src, int T, bool 
   return a;
 }
 
-void launch_multi(const Slab &s, const MultiArgs &a, int tile_rows, hipStream_t st) {
+void launch_multi(const Slab &s, const MultiArgs &a, int tile_rows, hipStream_t st, bool peer_form = false) {
   const dim3 grid(s.m_tiles_x * tile_rows), block(kMultiThreads);
+  if (peer_form) {
+    if (s.m_tx == 32) hipLaunchKernelGGL((d2q9_multi<32, 16, true>), grid, block, 0, st, a);
+    else if (s.m_ty == 16) hipLaunchKernelGGL((d2q9_multi<16, 16, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((d2q9_multi<16, 8, true>), grid, block, 0, st, a);
+    return;
+  }
   if (s.m_tx == 32) hipLaunchKernelGGL((d2q9_multi<32, 16>), grid, block, 0, st, a);
   else if (s.m_ty == 16) hipLaunchKernelGGL((d2q9_multi<16, 16>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((d2q9_multi<16, 8>), grid, block, 0, st, a);
@@ -734,6 +746,8 @@ struct RcclTransport {
 
 // PEER transport, consumer side: the launch that follows on `st` reads halo rows that exchange number `seq` fills
 int wait_halos(lbm_ctx *c, Slab &s, hipStream_t st, uint32_t seq) {
+  // (halo_sync 2 — the wait inside the consuming kernel — exists for the compact launch sets of d2q9_multi only;
+  // every other launch is ordered behind the wait kernel)
   if (c->halo_sync == 1) {
     HIP_TRY(hipStreamWaitValue32(st, s.halo_flags, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
     HIP_TRY(hipStreamWaitValue32(st, s.halo_flags + 1, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
@@ -966,7 +980,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (compact && kind == KIND_MULTI) {
         // ---- compact launch set: wait for the neighbours' rows of the latest exchange, then ONE launch of all tile
         // rows, the edge tile rows (tile row 0 and the tile rows from t_top up) first; they push this set's halo rows
-        if (int rc = wait_halos(c, s, s.s_main, c->halo_seq)) return rc;
+        if (c->halo_sync != 2)
+          if (int rc = wait_halos(c, s, s.s_main, c->halo_seq)) return rc;
         const int m = s.m_tiles_y;
         const int t_top = std::max(1, std::min(m, (s.rows - s.edge_rows) / s.m_ty));
         const int edge_trows = 1 + (m - t_top);
@@ -974,18 +989,19 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         a.partials = slot1;
         a.ty_begin = 0; a.ty_split = 1; a.ty_begin2 = t_top;     // workgroup rows 1 .. edge_trows-1: tile rows t_top ..
         a.ty_split2 = edge_trows; a.ty_begin3 = 1;               // then the interior tile rows 1 .. t_top-1
+        a.edge_blocks = edge_trows * s.m_tiles_x;
+        a.peer = s.d_peer;
+        if (c->halo_sync == 2) {
+          a.peer_mode |= 2;
+          a.wait_seq = c->halo_seq;
+        }
         if (!last) {
-          a.push_rows = s.row0;
-          a.edge_blocks = edge_trows * s.m_tiles_x;
-          a.push_lo = s.south.cells[src ^ 1] + (size_t)(s.row0 + s.south.rows) * s.row_stride;
-          a.push_hi = s.north.cells[src ^ 1];
-          a.flag_lo = s.south.flags + 1;
-          a.flag_hi = s.north.flags + 0;
-          a.ticket = s.halo_flags + 3;
+          a.peer_mode |= 1;
+          a.peer_buf = src ^ 1;
           a.seq = c->halo_seq + 1;
         }
         if (int rc = mark(s, 3, s.s_main)) return rc;
-        launch_multi(s, a, m, s.s_main);
+        launch_multi(s, a, m, s.s_main, true);
         HIP_TRY(hipGetLastError());
         if (int rc = mark(s, 4, s.s_main)) return rc;
         continue;
@@ -1180,6 +1196,7 @@ void free_slab(Slab &s) {
     if (l->flags) hipIpcCloseMemHandle(l->flags);
   }
   if (s.halo_flags) hipFree(s.halo_flags);
+  if (s.d_peer) hipFree(s.d_peer);
   if (s.av_tmp) hipFree(s.av_tmp);
   if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
   if (s.s_edge) hipStreamDestroy(s.s_edge);
@@ -1344,6 +1361,26 @@ int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *whi
   return LBM_OK;
 }
 
+// device-side description of a connected slab's neighbours for the fused push / wait of d2q9_multi
+int upload_multi_peer(Slab &s) {
+  MultiPeer h{};
+  for (int b = 0; b < 2; b++) {
+    h.push_lo[b] = s.south.cells[b] + (size_t)(s.row0 + s.south.rows) * s.row_stride;
+    h.push_hi[b] = s.north.cells[b];
+  }
+  h.flag_lo = s.south.flags + 1;  // this slab is the south neighbour's NORTH neighbour
+  h.flag_hi = s.north.flags + 0;
+  h.ticket = s.halo_flags + 3;
+  h.wait_flags = s.halo_flags;
+  h.wait_err = s.halo_flags + 2;
+  h.wait_ticks = kHaloWaitTicks;
+  h.push_rows = s.row0;
+  if (set_dev(s)) return LBM_ERR_HIP;
+  if (!s.d_peer && dev_alloc(&s.d_peer, 1)) return LBM_ERR_HIP;
+  HIP_TRY(hipMemcpy(s.d_peer, &h, sizeof h, hipMemcpyHostToDevice));
+  return LBM_OK;
+}
+
 // one process: every slab's neighbours are local slabs
 int connect_local_ring(lbm_ctx *c) {
   const int P = (int)c->slabs.size();
@@ -1353,6 +1390,7 @@ int connect_local_ring(lbm_ctx *c) {
     fill_peer_info(c->slabs[(s.index + 1) % P], no, false, nullptr);
     if (int rc = connect_link(s, s.south, so, "south")) return rc;
     if (int rc = connect_link(s, s.north, no, "north")) return rc;
+    if (int rc = upload_multi_peer(s)) return rc;
   }
   return LBM_OK;
 }
@@ -1419,6 +1457,7 @@ int lbm_connect_peers(lbm_ctx *c, const void *south_info, const void *north_info
   }
   s.south = south;
   s.north = north;
+  if (int rc = upload_multi_peer(s)) return rc;
   c->transport_eff = TRANSPORT_PEER;
   return LBM_OK;
 }
@@ -1808,9 +1847,21 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     c->grid_blocks = (int)value;
     return rebuild_geometry(c);
   }
-  if (!strcmp(key, "nt_stores")) { c->nt_stores = (int)value; return LBM_OK; }
-  if (!strcmp(key, "nt_loads")) { c->nt_loads = (int)value; return LBM_OK; }
-  if (!strcmp(key, "fuse")) { c->fuse = (int)value; return LBM_OK; }
+  if (!strcmp(key, "nt_stores")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "nt_stores must be -1 (auto), 0 or 1");
+    c->nt_stores = (int)value;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "nt_loads")) {
+    if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "nt_loads must be -1 (auto), 0, 1 or 2");
+    c->nt_loads = (int)value;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "fuse")) {
+    if (value < -1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be -1 (auto), 0, 1 (or 2), 3 or 4");
+    c->fuse = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "tile_shape")) {
     if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "tile_shape must be -1..2");
     if (int rc = sync_all(c)) return rc;
@@ -1851,7 +1902,8 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     return LBM_OK;
   }
   if (!strcmp(key, "halo_sync")) {
-    if (value != 0 && value != 1) return fail(LBM_ERR_ARG, "halo_sync must be 0 (wait kernel) or 1 (hipStreamWaitValue32)");
+    if (value < 0 || value > 2)
+      return fail(LBM_ERR_ARG, "halo_sync must be 0 (wait kernel), 1 (hipStreamWaitValue32) or 2 (inside the consuming kernel where it can)");
     if (value == 1) {
       int can = 0;
       for (const Slab &s : c->slabs) {

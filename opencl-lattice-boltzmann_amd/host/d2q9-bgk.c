@@ -17,6 +17,8 @@
  *   LBM_NO_OUTPUT=1                   skip writing the two .dat files
  *   LBM_HOST_INIT=1                   build the initial state on the host and upload it, as the
  *                                     reference does (default: initialise on the device)
+ *   LBM_PARSER_THREADS=n, LBM_WRITER_THREADS=n   threads of the obstacle-file scan / of the final_state formatter
+ *                                     (default: up to 16, at least 64 KB of obstacle text per thread)
  */
 #include <errno.h>
 #include <fcntl.h>
@@ -153,26 +155,23 @@ static void load_params(const char *paramfile, lbm_params *params)
   unmap_file(&t);
 }
 
-static void load_obstacles(const char *obstaclefile, lbm_params *params, int32_t *obstacles)
+/* The obstacle records, serially: the statement of the reference's loop (d2q9-bgk.c:553-591) on the mapped text.
+ * Used for small files and whenever the parallel scan below meets anything that is not a plain integer token, so that
+ * malformed files fail exactly where and how the reference's fscanf("%d %d %d\n") loop fails. */
+static long scan_obstacles_serial(text_t *t, const lbm_params *params, int32_t *obstacles)
 {
-  char message[1024];
-  text_t t;
-  if (map_file(obstaclefile, &t) != 0) {
-    snprintf(message, sizeof message, "could not open input obstacles file: %s", obstaclefile);
-    die(message, __LINE__, __FILE__);
-  }
-  long free_cells = (long)params->nx * params->ny;
+  long blocked_cells = 0;
   for (;;) {
     int xx = 0, yy = 0, blocked = 0;
     /* fscanf("%d %d %d\n"): EOF only when the input ends before the first conversion */
-    int r0 = scan_int(&t, &xx);
+    int r0 = scan_int(t, &xx);
     if (r0 == EOF) break;
     int retval = r0;
     if (retval == 1) {
-      int r1 = scan_int(&t, &yy);
+      int r1 = scan_int(t, &yy);
       if (r1 == 1) {
         retval = 2;
-        if (scan_int(&t, &blocked) == 1) retval = 3;
+        if (scan_int(t, &blocked) == 1) retval = 3;
       }
     }
     /* some checks, d2q9-bgk.c:573-580 */
@@ -181,11 +180,163 @@ static void load_obstacles(const char *obstaclefile, lbm_params *params, int32_t
     if (yy < 0 || yy > params->ny - 1) die("obstacle y-coord out of range", __LINE__, __FILE__);
     if (blocked != 1) die("obstacle blocked value should be 1", __LINE__, __FILE__);
     /* a cell listed twice is one blocked cell, d2q9-bgk.c:583-585 */
-    if (!obstacles[(size_t)yy * params->nx + xx]) free_cells--;
+    if (!obstacles[(size_t)yy * params->nx + xx]) blocked_cells++;
     obstacles[(size_t)yy * params->nx + xx] = blocked;
   }
+  return blocked_cells;
+}
+
+/* Parallel scan of a large obstacle file (the tiled-up 8192x8192 geometry is 4 MB of text, ~330 000 records): the
+ * mapped text is cut at whitespace into one byte range per thread; pass 1 counts the integer tokens of every range
+ * (records are token triples, wherever the line breaks are — exactly fscanf's view), pass 2 lets every thread convert
+ * the records whose first token lies in its range.  A cell is claimed with an atomic exchange, so duplicates are
+ * counted once without a second pass.  The first offending record in FILE order decides the error, as in the
+ * serial loop. */
+enum { OB_OK = 0, OB_FIELDS = 1, OB_XRANGE = 2, OB_YRANGE = 3, OB_VALUE = 4 };
+
+typedef struct {
+  const char *beg, *end, *file_end;
+  const lbm_params *params;
+  int32_t *obstacles;
+  long ntokens;        /* pass 1: integer tokens in [beg, end) */
+  int malformed;       /* pass 1: a token that is not a plain integer */
+  long first_token;    /* pass 2: global index of the range's first token */
+  long blocked_cells;  /* pass 2: cells this thread claimed first */
+  long err_record;     /* pass 2: index of the first bad record seen by this thread, or -1 */
+  int err_kind;
+} ob_job;
+
+static int is_space_ch(char ch) { return ch == ' ' || (ch >= '\t' && ch <= '\r'); }
+
+static void *ob_count_tokens(void *arg)
+{
+  ob_job *j = (ob_job *)arg;
+  const char *p = j->beg;
+  long n = 0;
+  while (p < j->end) {
+    while (p < j->end && is_space_ch(*p)) p++;
+    if (p >= j->end) break;
+    const char *q = p;
+    if (*q == '+' || *q == '-') q++;
+    const char *digits = q;
+    while (q < j->file_end && *q >= '0' && *q <= '9') q++;
+    if (q == digits || (q < j->file_end && !is_space_ch(*q))) { j->malformed = 1; break; }
+    n++;
+    p = q;
+  }
+  j->ntokens = n;
+  return NULL;
+}
+
+/* next integer token at or after *pp (tokens are known to be well formed); 0 at the end of the file */
+static int ob_next_int(const char **pp, const char *file_end, int *out)
+{
+  const char *p = *pp;
+  while (p < file_end && is_space_ch(*p)) p++;
+  if (p >= file_end) return 0;
+  int neg = 0;
+  if (*p == '+' || *p == '-') { neg = (*p == '-'); p++; }
+  long v = 0;
+  while (p < file_end && *p >= '0' && *p <= '9') {
+    if (v < (1L << 40)) v = v * 10 + (*p - '0');
+    p++;
+  }
+  *out = (int)(neg ? -v : v);
+  *pp = p;
+  return 1;
+}
+
+static void *ob_convert_records(void *arg)
+{
+  ob_job *j = (ob_job *)arg;
+  const char *p = j->beg;
+  long tok = j->first_token;
+  int skip = (int)((3 - tok % 3) % 3), dummy;   /* tokens that finish a record begun in an earlier range */
+  long left = j->ntokens;
+  for (; skip > 0 && left > 0; skip--, left--, tok++) ob_next_int(&p, j->file_end, &dummy);
+  j->err_record = -1;
+  while (left > 0) {
+    /* a record whose first token is in this range; its other two may lie beyond `end` */
+    int v[3], got = 0;
+    while (got < 3 && ob_next_int(&p, j->file_end, &v[got])) got++;
+    const long record = tok / 3;
+    int kind = OB_OK;
+    if (got != 3) kind = OB_FIELDS;
+    else if (v[0] < 0 || v[0] > j->params->nx - 1) kind = OB_XRANGE;
+    else if (v[1] < 0 || v[1] > j->params->ny - 1) kind = OB_YRANGE;
+    else if (v[2] != 1) kind = OB_VALUE;
+    if (kind != OB_OK) { j->err_record = record; j->err_kind = kind; return NULL; }
+    if (__atomic_exchange_n(&j->obstacles[(size_t)v[1] * j->params->nx + v[0]], 1, __ATOMIC_RELAXED) == 0) j->blocked_cells++;
+    tok += 3;
+    left -= 3;
+  }
+  return NULL;
+}
+
+static void run_jobs(ob_job *jobs, int n, void *(*fn)(void *))
+{
+  pthread_t tids[64];
+  for (int t = 0; t < n; t++)
+    if (pthread_create(&tids[t], NULL, fn, &jobs[t]) != 0) { fn(&jobs[t]); tids[t] = 0; }
+  for (int t = 0; t < n; t++)
+    if (tids[t]) pthread_join(tids[t], NULL);
+}
+
+static void load_obstacles(const char *obstaclefile, lbm_params *params, int32_t *obstacles)
+{
+  char message[1024];
+  text_t t;
+  if (map_file(obstaclefile, &t) != 0) {
+    snprintf(message, sizeof message, "could not open input obstacles file: %s", obstaclefile);
+    die(message, __LINE__, __FILE__);
+  }
+  long blocked_cells = -1;
+  long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+  int nthreads = (int)(ncpu < 1 ? 1 : (ncpu > 16 ? 16 : ncpu));
+  if (getenv("LBM_PARSER_THREADS")) nthreads = atoi(getenv("LBM_PARSER_THREADS"));
+  if (nthreads > 64) nthreads = 64;
+  if ((size_t)nthreads > t.len / 65536) nthreads = (int)(t.len / 65536);  /* at least 64 KB of text per thread */
+  if (getenv("LBM_PARSER_THREADS") && atoi(getenv("LBM_PARSER_THREADS")) > 1 && t.len > 0)  /* tests: force the parallel path */
+    nthreads = atoi(getenv("LBM_PARSER_THREADS")) > 64 ? 64 : atoi(getenv("LBM_PARSER_THREADS"));
+  if (nthreads > 1) {
+    ob_job jobs[64];
+    memset(jobs, 0, sizeof jobs);
+    const char *cut = t.base;
+    for (int i = 0; i < nthreads; i++) {
+      const char *stop = (i == nthreads - 1) ? t.end : t.base + (size_t)((double)t.len * (i + 1) / nthreads);
+      if (stop < cut) stop = cut;
+      while (stop < t.end && !is_space_ch(*stop)) stop++;   /* never inside a token */
+      jobs[i].beg = cut; jobs[i].end = stop; jobs[i].file_end = t.end;
+      jobs[i].params = params; jobs[i].obstacles = obstacles;
+      cut = stop;
+    }
+    run_jobs(jobs, nthreads, ob_count_tokens);
+    int malformed = 0;
+    long total = 0;
+    for (int i = 0; i < nthreads; i++) {
+      malformed |= jobs[i].malformed;
+      jobs[i].first_token = total;
+      total += jobs[i].ntokens;
+    }
+    if (!malformed) {
+      run_jobs(jobs, nthreads, ob_convert_records);
+      long bad = -1;
+      int kind = OB_OK;
+      blocked_cells = 0;
+      for (int i = 0; i < nthreads; i++) {
+        blocked_cells += jobs[i].blocked_cells;
+        if (jobs[i].err_record >= 0 && (bad < 0 || jobs[i].err_record < bad)) { bad = jobs[i].err_record; kind = jobs[i].err_kind; }
+      }
+      /* same checks, same messages, first offending record first (d2q9-bgk.c:573-580) */
+      if (kind == OB_FIELDS) die("expected 3 values per line in obstacle file", __LINE__, __FILE__);
+      if (kind == OB_XRANGE) die("obstacle x-coord out of range", __LINE__, __FILE__);
+      if (kind == OB_YRANGE) die("obstacle y-coord out of range", __LINE__, __FILE__);
+      if (kind == OB_VALUE) die("obstacle blocked value should be 1", __LINE__, __FILE__);
+    }
+  }
+  if (blocked_cells < 0) blocked_cells = scan_obstacles_serial(&t, params, obstacles);
   unmap_file(&t);
-  params->free_cells_inv = 1.0f / free_cells;
+  params->free_cells_inv = 1.0f / ((long)params->nx * params->ny - blocked_cells);
 }
 
 /* ---- output stage: d2q9-bgk.c:772-856 ---------------------------------------------------------- */

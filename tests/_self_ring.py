@@ -33,9 +33,9 @@ with lbm_amd.LBM(p, ob) as sim:
 lbm_amd.set_default("force_halo", 1)
 lbm_amd.set_default("transport", transport)
 code = lbm_amd.TRANSPORTS[transport]
-# peer: consumer-side wait by kernel / by hipStreamWaitValue32, and the launch sets of d2q9_multi compact (one launch,
+# peer: consumer-side wait by kernel / by hipStreamWaitValue32 / inside the consuming kernel (compact sets), and the launch sets of d2q9_multi compact (one launch,
 # the edge tiles push the halo rows themselves) / as edge launch + interior launch + push kernel
-variants = ((0, -1), (1, -1), (0, 0)) if transport == "peer" else ((0, -1),)
+variants = ((0, -1), (1, -1), (2, -1), (0, 0)) if transport == "peer" else ((0, -1),)
 for (sync, compact) in variants:
     for (fuse, ms) in ((0, 0), (1, 0), (3, 0), (4, 0), (0, 8), (0, 5)):  # 1 / 2 / 3 / 4 / 8 / 5 timesteps per launch set (halo depth 8)
         kw = dict(rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) if transport == "rccl" else dict(devices=[0])
