@@ -361,6 +361,146 @@ __global__ __launch_bounds__(kBlock) void d2q9_step(const StepArgs a) {
   block_store_partial(tot_u, a.partials);
 }
 
+// ---- peer-halo transport: push kernel + flag words ------------------------------------------------
+// A slab's edge rows go straight into the ring neighbours' halo rows (peer-mapped memory: the same process, another
+// device with peer access, or another process through HIP IPC), followed by a sequence number in the neighbour's
+// flag word.  Protocol (csrc/lbm_hip.cpp, exchange_halos): the consumer waits for flag >= seq before the launch that
+// reads the halo rows; that the producer may overwrite them again follows from the data dependencies of the ring
+// (its next push comes after its next edge launch, which waited for this consumer's previous push, which came
+// after the consumer's last reader of those rows).
+struct PushArgs {
+  const float *src_lo, *src_hi;   // this slab's bottom / top edge rows (halo_depth rows each, contiguous)
+  float *dst_lo, *dst_hi;         // the south neighbour's top halo rows / the north neighbour's bottom halo rows
+  unsigned long long n4;          // float4 per block
+  uint32_t *flag_lo, *flag_hi;    // the neighbours' flag words for pushes arriving from this side
+  uint32_t seq;                   // sequence number of this exchange
+  unsigned *ticket;               // workgroups done (reset by the last one)
+};
+
+__device__ __forceinline__ void flag_store_system(uint32_t *flag, uint32_t v) {
+  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint32_t flag_load_system(const uint32_t *flag) {
+  return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// WRITE-THROUGH stores (sc0 sc1: system scope, nothing stays dirty in this XCD's L2).  The pushed halo rows are made
+// visible by these stores themselves plus each storing wave's s_waitcnt vmcnt(0) — not by release fences: a fence writes
+// back (and, as __threadfence_system, invalidates) the whole L2 of the XCD, which the interior launch running beside
+// the push is busy filling (first version, one fence per thread: 8192x1024 slab 44.1 instead of 38.1 us/step).
+// Written as two 8-byte system-scope relaxed atomic stores, which the compiler turns into global_store_dwordx2 sc0 sc1,
+// NOT as inline assembly: the hazard recognizer does not look inside an asm block, and a hand-written
+// global_store_dwordx4 there went wrong twice — issued right behind the v_readfirstlane that produced its SGPR base (a
+// vector-memory instruction may read a VALU-written SGPR only five wait states later: stale base, GPU memory fault) and
+// right in front of a VALU instruction that re-used its data registers (a store of more than 8 bytes reads its data
+// late: seven of eight pushed rows arrived corrupted).
+typedef __attribute__((address_space(1))) unsigned long long global_u64;  // a pointer known to be global memory: global_store, not flat_store
+__device__ __forceinline__ void store4_through(float *p, v4f v) {
+  global_u64 *q = (global_u64 *)(unsigned long long)p;
+  const unsigned long long lo = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+  const unsigned long long hi = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+  __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// a value every lane holds alike, moved to scalar registers (what the compiler cannot prove for values loaded through
+// the late argument pointer)
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+// the same from (wave-uniform base pointer) + (the lane's 32-bit byte offset): the SGPR-base addressing form
+__device__ __forceinline__ void store4_through_sbase(float *uniform_base, unsigned byte_off, v4f v) {
+  store4_through(reinterpret_cast<float *>(reinterpret_cast<char *>(uniform_base) + byte_off), v);
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
+// The last workgroup of `expected` to arrive publishes the sequence number.  Precondition: every wave of the calling
+// workgroup has drained its write-through stores (drain_stores) before the barrier in here.
+__device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned expected, uint32_t *flag_a, uint32_t *flag_b, uint32_t seq) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == expected - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next user starts after this kernel has ended
+      if (flag_a) flag_store_system(flag_a, seq);
+      if (flag_b) flag_store_system(flag_b, seq);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void halo_push(const PushArgs a) {
+  const unsigned half = gridDim.x >> 1;  // first half of the workgroups: bottom rows, second half: top rows
+  const bool hi = blockIdx.x >= half;
+  const v4f *src = reinterpret_cast<const v4f *>(hi ? a.src_hi : a.src_lo);
+  float *dst = hi ? a.dst_hi : a.dst_lo;
+  const unsigned b = hi ? blockIdx.x - half : blockIdx.x;
+  for (size_t i = (size_t)b * kBlock + threadIdx.x; i < a.n4; i += (size_t)half * kBlock) store4_through(dst + 4 * i, src[i]);
+  drain_stores();
+  publish_when_last(a.ticket, gridDim.x, a.flag_lo, a.flag_hi, a.seq);
+}
+
+// Consumer side: one wave, lanes 0 and 1 poll the two flag words until both have reached `seq`.  The spin is
+// BOUNDED (timeout in 100-MHz ticks of s_memrealtime): a neighbour that never arrives sets the error word, which
+// lbm_sync reports, instead of hanging the GPU.  The launch that follows starts with the usual kernel-start acquire.
+
+// What a slab's kernels need to know about its ring neighbours, device-resident (filled once the ring is connected):
+// as kernel arguments these pointers stayed live in SGPRs to the end of the kernel (d2q9_multi: 92 instead of 76, which
+// costs the 16x16 / 16x8 tiles their second workgroup per CU — more than 80 SGPRs admit 28 waves per CU, not 32).
+struct HaloPeer {
+  float *push[2][2];               // [side][grid]: side 0 = the south neighbour's top halo rows (this slab's bottom edge rows go
+                                   // there), side 1 = the north neighbour's bottom halo rows (this slab's top edge rows)
+  uint32_t *flag_lo, *flag_hi;     // the neighbours' flag words for pushes arriving from this slab
+  unsigned *ticket;
+  const uint32_t *wait_flags;      // this slab's own flag words
+  uint32_t *wait_err;
+  unsigned long long wait_ticks;
+  int push_rows;                   // halo depth H
+  int row_lo0, row_hi0;            // stored rows of the first bottom edge row / the first top edge row (the rows that are pushed)
+};
+
+// The kernel's own argument block, re-read where it is used: fields needed only at the very start or the very end of
+// a long kernel otherwise sit in SGPRs all the way through (the asm hides that this is the preloaded argument copy).
+template <class Args>
+__device__ __forceinline__ const Args *late_args() {
+  unsigned long long p = (unsigned long long)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return reinterpret_cast<const Args *>(p);
+}
+
+// bounded spin of lanes 0 and 1 on the two flag words (see halo_wait)
+__device__ __forceinline__ void spin_on_flags(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+  if (threadIdx.x < 2) {
+    const uint32_t *f = flags + threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(flag_load_system(f) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
+        atomicOr(err, 1u);
+        break;
+      }
+    }
+  }
+}
+
+__global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+  spin_on_flags(flags, seq, err, timeout);
+}
+
+
+// the last of `expected` waves (each after draining its own write-through stores) publishes the sequence number
+__device__ __forceinline__ void publish_wave_when_last(const HaloPeer *pp, unsigned expected, uint32_t seq) {
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned t = __hip_atomic_fetch_add(pp->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == expected - 1) {
+      __hip_atomic_store(pp->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag_store_system(pp->flag_lo, seq);
+      flag_store_system(pp->flag_hi, seq);
+    }
+  }
+}
+
 // ---- two timesteps per launch (temporal blocking) ------------------------------------------------
 // One wave64 = one work unit: a strip of 64 float4-lanes sweeping `chunk_rows` grid rows upward.  Per
 // row it (1) gathers the source rows and collides once (the intermediate state I, step t+1) and keeps I
@@ -389,7 +529,78 @@ struct Step2Args {
   int accel_row_b;             // a second stored copy of it (a slab that is its own ring neighbour), else -1
   int accel_next;              // apply the following step's accelerate_flow to the output row ny-2
   float omega, aw1, aw2;
+  // Compact launch sets (peer transport; PUSH instantiations of d2q9_step3/3p/4/4p): ONE launch per launch set.  Its
+  // first edge_units workgroups work through the edge schedule (the halo_depth rows at either end of the slab — what
+  // the ring neighbours need), the others through the interior schedule above; an edge unit stores its output rows a
+  // second time, write-through, into the neighbour's halo rows, and the last edge wave to finish raises the neighbours'
+  // flag words to seq (peer_mode bit 0; without it — the last launch set of a run — the same launch, no push).
+  const int *edge_chunk_start;   // chunk table of the edge schedule {bottom edge, (interior: skipped), top edge, ...}
+  int edge_nchunks, edge_units, edge_skip;
+  int edge_partial_off;          // edge unit u keeps its velocity sums in slot edge_partial_off + u
+  const struct HaloPeer *peer;
+  uint32_t seq;
+  int peer_mode, peer_buf;       // peer_buf: which of the neighbours' two grids the pushed rows go to
 };
+
+// Which work unit a workgroup has (compact launch sets: edge schedule first).  All wave-uniform.
+struct UnitSel {
+  const int *chunk_start;
+  int bid, nbands, units_per_band, skip, partial_off;
+  bool edge;
+};
+template <bool PUSH>
+__device__ __forceinline__ UnitSel select_unit(const Step2Args &a, int edge_wgs) {
+  UnitSel u{a.chunk_start, (int)blockIdx.x, a.nbands, a.units_per_band, a.skip_chunk, 0, false};
+  if constexpr (PUSH) {
+    if (u.bid < edge_wgs) {
+      u.edge = true;
+      u.chunk_start = a.edge_chunk_start;
+      u.nbands = 1;
+      u.units_per_band = edge_wgs;
+      u.skip = a.edge_skip;
+      u.partial_off = a.edge_partial_off;
+    } else {
+      u.bid -= edge_wgs;
+    }
+  }
+  return u;
+}
+
+// An edge unit's output rows a second time: into the ring neighbour's halo rows, write-through.  Done after the sweep,
+// from the rows the wave has just stored (every lane re-reads exactly what it wrote itself: program order makes its own
+// stores visible to it), so that the row loop of the PUSH instantiations is the row loop of the plain kernels — pushing
+// from inside the loop cost the four-step kernel 47-66 spilled registers.  The rows of an edge chunk are, by
+// construction, halo_depth rows at the bottom (stored rows row_lo0 ..) or at the top (row_hi0 ..) of the slab; a chunk
+// that is neither raises the slab's error word instead of storing anywhere (lbm_sync reports it).
+__device__ __forceinline__ void push_chunk(const Step2Args *la, int ys, int ye, int xcol, bool owner) {
+  drain_stores();
+  const HaloPeer *pp = uniform_ptr(la->peer);
+  const int hi0 = __builtin_amdgcn_readfirstlane(pp->row_hi0);
+  const int lo0 = __builtin_amdgcn_readfirstlane(pp->row_lo0);
+  const int rows = __builtin_amdgcn_readfirstlane(pp->push_rows);
+  const int buf = __builtin_amdgcn_readfirstlane(la->peer_buf) & 1;
+  const int side = ys >= hi0 ? 1 : 0;
+  const int base = side ? hi0 : lo0;
+  if (ys < base || ye > base + rows) {
+    if ((threadIdx.x & 63) == 0) atomicOr(pp->wait_err, 2u);
+    return;
+  }
+  const size_t rs = la->row_stride, ps = la->plane_stride;
+  const float *own = la->dst + xcol;
+  float *peer = pp->push[side][buf] + xcol;
+  if (owner) {
+    for (int y = ys; y < ye; y++) {
+      const float *src = own + (size_t)y * rs;
+      float *dst = peer + (size_t)(y - base) * rs;
+      v4f v[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) v[k] = *reinterpret_cast<const v4f *>(src + k * ps);
+#pragma unroll
+      for (int k = 0; k < 9; k++) store4_through(dst + k * ps, v[k]);
+    }
+  }
+  drain_stores();
+}
 
 struct RowLoads {
   float4 c[9];
@@ -724,18 +935,27 @@ __device__ __forceinline__ void lds_window_put(v4f *w, int par, const float (&to
 
 // WLDS: the two windows live in LDS (two waves per SIMD) instead of registers (one wave per SIMD).
 // NBUF: row-sets of source loads in flight (2 = ping-pong as in d2q9_step2, 1 = the next row only).
-template <bool NT, int NTL = 0, bool WLDS = false, int NBUF = 2>
+template <bool NT, int NTL = 0, bool WLDS = false, int NBUF = 2, bool PUSH = false>
 __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *partials3) {
   __shared__ v4f win[WLDS ? 2 * kWinSlots * 64 : 1];
   const int lane = threadIdx.x;
-  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
-  if (slot >= a.units_per_band) return;
-  const int unit = band * a.units_per_band + slot;
-  const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
-  const int ys = a.chunk_start[chunk];
-  const int ye = a.chunk_start[chunk + 1];
-  if (ys >= ye || chunk == a.skip_chunk) {
+  const UnitSel us = select_unit<PUSH>(a, a.edge_units);
+  // decided once (re-reading it from the argument block in every row iteration drained the wave's loads each time:
+  // 8192x4096 slab 246 instead of 281 GLUPS)
+  const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
+  if (slot >= us.units_per_band) return;
+  const int unit0 = band * us.units_per_band + slot;
+  const int chunk = unit0 / a.strips, strip = unit0 - chunk * a.strips;
+  const int unit = unit0 + us.partial_off;  // slot of the velocity sums
+  const int ys = us.chunk_start[chunk];
+  const int ye = us.chunk_start[chunk + 1];
+  if (ys >= ye || chunk == us.skip) {
     if (lane == 0) a.partials1[unit] = a.partials2[unit] = partials3[unit] = 0.f;
+    if constexpr (PUSH) {
+      const Step2Args *la = late_args<Step2Args>();
+      if (us.edge && (la->peer_mode & 1)) publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
     return;
   }
   const int q4 = a.nx >> 2;
@@ -837,6 +1057,13 @@ __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *parti
     a.partials2[unit] = sum2;
     partials3[unit] = sum3;
   }
+  if constexpr (PUSH) {
+    const Step2Args *la = late_args<Step2Args>();
+    if (do_push) {
+      push_chunk(la, ys, ye, xcol, owner);
+      publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
+  }
 }
 
 // ---- three timesteps per launch, chunk pairs ------------------------------------------------------------
@@ -862,24 +1089,30 @@ __device__ __forceinline__ void lds_put_trail(v4f *w, int par, const float (&top
   lds_put(w, 5 + 3 * par, t);
 }
 
-template <bool NT, int NTL = 0>
+template <bool NT, int NTL = 0, bool PUSH = false>
 __global__ __launch_bounds__(128) void d2q9_step3p(const Step2Args a, float *partials3) {
   __shared__ v4f win[2 * 2 * kWinSlots * 64];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
-  if (slot >= a.units_per_band) return;  // units_per_band counts chunk PAIRS x strips here
-  const int punit = band * a.units_per_band + slot;
+  const UnitSel us = select_unit<PUSH>(a, a.edge_units / 2);
+  const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
+  if (slot >= us.units_per_band) return;  // units_per_band counts chunk PAIRS x strips here
+  const int punit = band * us.units_per_band + slot;
   const int pair = punit / a.strips, strip = punit - pair * a.strips;
   const int chunk = 2 * pair + wv;
-  const int unit = chunk * a.strips + strip;  // slot of the partial sums, as in d2q9_step3
-  const int ys = a.chunk_start[chunk];
-  const int ye = a.chunk_start[chunk + 1];
-  const int pys = a.chunk_start[chunk ^ 1], pye = a.chunk_start[(chunk ^ 1) + 1];
-  const bool empty = ys >= ye || chunk == a.skip_chunk;
-  const bool paired = !empty && pys < pye && (chunk ^ 1) != a.skip_chunk;  // the same on both waves
+  const int unit = chunk * a.strips + strip + us.partial_off;  // slot of the partial sums, as in d2q9_step3
+  const int ys = us.chunk_start[chunk];
+  const int ye = us.chunk_start[chunk + 1];
+  const int pys = us.chunk_start[chunk ^ 1], pye = us.chunk_start[(chunk ^ 1) + 1];
+  const bool empty = ys >= ye || chunk == us.skip;
+  const bool paired = !empty && pys < pye && (chunk ^ 1) != us.skip;  // the same on both waves
   if (empty) {
     if (lane == 0) a.partials1[unit] = a.partials2[unit] = partials3[unit] = 0.f;
+    if constexpr (PUSH) {
+      const Step2Args *la = late_args<Step2Args>();
+      if (us.edge && (la->peer_mode & 1)) publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
     return;  // the partner then runs alone and meets no barrier
   }
   const int q4 = a.nx >> 2;
@@ -964,6 +1197,13 @@ __global__ __launch_bounds__(128) void d2q9_step3p(const Step2Args a, float *par
     a.partials2[unit] = sum2;
     partials3[unit] = sum3;
   }
+  if constexpr (PUSH) {
+    const Step2Args *la = late_args<Step2Args>();
+    if (do_push) {
+      push_chunk(la, ys, ye, xcol, owner);
+      publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
+  }
 }
 
 // ---- four timesteps per launch ------------------------------------------------------------------------
@@ -974,18 +1214,27 @@ __global__ __launch_bounds__(128) void d2q9_step3p(const Step2Args a, float *par
 // 160 KB), and the row loads use SGPR-base addressing: together they bring the kernel from 254 VGPRs + 12 spilled
 // to 253 and none.  The spills cost 17 % (8192x8192: 249 -> 274 GLUPS with the LDS planes, -> 291 with both).
 constexpr int kW3Lds = 2;
-template <bool NT, int NTL = 0>
+template <bool NT, int NTL = 0, bool PUSH = false>
 __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *partials3, float *partials4) {
   __shared__ v4f win[(2 * kWinSlots + kW3Lds) * 64];
   const int lane = threadIdx.x;
-  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
-  if (slot >= a.units_per_band) return;
-  const int unit = band * a.units_per_band + slot;
-  const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
-  const int ys = a.chunk_start[chunk];
-  const int ye = a.chunk_start[chunk + 1];
-  if (ys >= ye || chunk == a.skip_chunk) {
+  const UnitSel us = select_unit<PUSH>(a, a.edge_units);
+  // decided once (re-reading it from the argument block in every row iteration drained the wave's loads each time:
+  // 8192x4096 slab 246 instead of 281 GLUPS)
+  const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
+  if (slot >= us.units_per_band) return;
+  const int unit0 = band * us.units_per_band + slot;
+  const int chunk = unit0 / a.strips, strip = unit0 - chunk * a.strips;
+  const int unit = unit0 + us.partial_off;  // slot of the velocity sums
+  const int ys = us.chunk_start[chunk];
+  const int ye = us.chunk_start[chunk + 1];
+  if (ys >= ye || chunk == us.skip) {
     if (lane == 0) a.partials1[unit] = a.partials2[unit] = partials3[unit] = partials4[unit] = 0.f;
+    if constexpr (PUSH) {
+      const Step2Args *la = late_args<Step2Args>();
+      if (us.edge && (la->peer_mode & 1)) publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
     return;
   }
   const int q4 = a.nx >> 2;
@@ -1079,6 +1328,13 @@ __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *pa
     partials3[unit] = sum3;
     partials4[unit] = sum4;
   }
+  if constexpr (PUSH) {
+    const Step2Args *la = late_args<Step2Args>();
+    if (do_push) {
+      push_chunk(la, ys, ye, xcol, owner);
+      publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
+  }
 }
 
 // ---- four timesteps per launch, chunk pairs -------------------------------------------------------------
@@ -1087,25 +1343,31 @@ __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *pa
 // level — levels 1 and 2 into the trail slots of the partner's LDS windows (iterations 3 and 4), level 3 through
 // the partner's window-2 trail slots once its own level-3 gather has consumed them (iteration 5, two barriers) and
 // from there into the register window.  n+3 iterations and 4n+6 collision passes per chunk instead of n+6 and 4n+12.
-template <bool NT, int NTL = 0>
+template <bool NT, int NTL = 0, bool PUSH = false>
 __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *partials3, float *partials4) {
   constexpr int kWave = (2 * kWinSlots + kW3Lds) * 64;  // LDS float4s per wave
   __shared__ v4f win[2 * kWave];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
-  if (slot >= a.units_per_band) return;  // units_per_band counts chunk PAIRS x strips here
-  const int punit = band * a.units_per_band + slot;
+  const UnitSel us = select_unit<PUSH>(a, a.edge_units / 2);
+  const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
+  if (slot >= us.units_per_band) return;  // units_per_band counts chunk PAIRS x strips here
+  const int punit = band * us.units_per_band + slot;
   const int pair = punit / a.strips, strip = punit - pair * a.strips;
   const int chunk = 2 * pair + wv;
-  const int unit = chunk * a.strips + strip;
-  const int ys = a.chunk_start[chunk];
-  const int ye = a.chunk_start[chunk + 1];
-  const int pys = a.chunk_start[chunk ^ 1], pye = a.chunk_start[(chunk ^ 1) + 1];
-  const bool empty = ys >= ye || chunk == a.skip_chunk;
-  const bool paired = !empty && pys < pye && (chunk ^ 1) != a.skip_chunk;  // the same on both waves
+  const int unit = chunk * a.strips + strip + us.partial_off;
+  const int ys = us.chunk_start[chunk];
+  const int ye = us.chunk_start[chunk + 1];
+  const int pys = us.chunk_start[chunk ^ 1], pye = us.chunk_start[(chunk ^ 1) + 1];
+  const bool empty = ys >= ye || chunk == us.skip;
+  const bool paired = !empty && pys < pye && (chunk ^ 1) != us.skip;  // the same on both waves
   if (empty) {
     if (lane == 0) a.partials1[unit] = a.partials2[unit] = partials3[unit] = partials4[unit] = 0.f;
+    if constexpr (PUSH) {
+      const Step2Args *la = late_args<Step2Args>();
+      if (us.edge && (la->peer_mode & 1)) publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
     return;
   }
   const int q4 = a.nx >> 2;
@@ -1232,70 +1494,14 @@ __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *
     partials3[unit] = sum3;
     partials4[unit] = sum4;
   }
-}
-
-// ---- peer-halo transport: push kernel + flag words ------------------------------------------------
-// A slab's edge rows go straight into the ring neighbours' halo rows (peer-mapped memory: the same process, another
-// device with peer access, or another process through HIP IPC), followed by a sequence number in the neighbour's
-// flag word.  Protocol (csrc/lbm_hip.cpp, exchange_halos): the consumer waits for flag >= seq before the launch that
-// reads the halo rows; that the producer may overwrite them again follows from the data dependencies of the ring
-// (its next push comes after its next edge launch, which waited for this consumer's previous push, which came
-// after the consumer's last reader of those rows).
-struct PushArgs {
-  const float *src_lo, *src_hi;   // this slab's bottom / top edge rows (halo_depth rows each, contiguous)
-  float *dst_lo, *dst_hi;         // the south neighbour's top halo rows / the north neighbour's bottom halo rows
-  unsigned long long n4;          // float4 per block
-  uint32_t *flag_lo, *flag_hi;    // the neighbours' flag words for pushes arriving from this side
-  uint32_t seq;                   // sequence number of this exchange
-  unsigned *ticket;               // workgroups done (reset by the last one)
-};
-
-__device__ __forceinline__ void flag_store_system(uint32_t *flag, uint32_t v) {
-  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ uint32_t flag_load_system(const uint32_t *flag) {
-  return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// 16-byte WRITE-THROUGH store (sc0 sc1: system scope, nothing stays dirty in this XCD's L2).  The pushed halo rows
-// are made visible by these stores themselves plus each storing wave's s_waitcnt vmcnt(0) — not by release fences:
-// a fence writes back (and, as __threadfence_system, invalidates) the whole L2 of the XCD, which the interior launch
-// running beside the push is busy filling (first version, one fence per thread: 8192x1024 slab 44.1 instead of 38.1
-// us/step, gpurun_out r02/ab_ring1.txt).
-__device__ __forceinline__ void store4_through(float *p, v4f v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// The last workgroup of `expected` to arrive publishes the sequence number.  Precondition: every wave of the calling
-// workgroup has drained its write-through stores (drain_stores) before the barrier in here.
-__device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned expected, uint32_t *flag_a, uint32_t *flag_b, uint32_t seq) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == expected - 1) {
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next user starts after this kernel has ended
-      if (flag_a) flag_store_system(flag_a, seq);
-      if (flag_b) flag_store_system(flag_b, seq);
+  if constexpr (PUSH) {
+    const Step2Args *la = late_args<Step2Args>();
+    if (do_push) {
+      push_chunk(la, ys, ye, xcol, owner);
+      publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
     }
   }
 }
-
-__global__ __launch_bounds__(kBlock) void halo_push(const PushArgs a) {
-  const unsigned half = gridDim.x >> 1;  // first half of the workgroups: bottom rows, second half: top rows
-  const bool hi = blockIdx.x >= half;
-  const v4f *src = reinterpret_cast<const v4f *>(hi ? a.src_hi : a.src_lo);
-  float *dst = hi ? a.dst_hi : a.dst_lo;
-  const unsigned b = hi ? blockIdx.x - half : blockIdx.x;
-  for (size_t i = (size_t)b * kBlock + threadIdx.x; i < a.n4; i += (size_t)half * kBlock) store4_through(dst + 4 * i, src[i]);
-  drain_stores();
-  publish_when_last(a.ticket, gridDim.x, a.flag_lo, a.flag_hi, a.seq);
-}
-
-// Consumer side: one wave, lanes 0 and 1 poll the two flag words until both have reached `seq`.  The spin is
-// BOUNDED (timeout in 100-MHz ticks of s_memrealtime): a neighbour that never arrives sets the error word, which
-// lbm_sync reports, instead of hanging the GPU.  The launch that follows starts with the usual kernel-start acquire.
-__global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout);
 
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------
 // Grids of a few hundred cells a side are bound by launch latency, not bandwidth (one step of 128x128 is
@@ -1332,51 +1538,12 @@ struct MultiArgs {
   // neighbours' halo rows, and the last of them to finish raises the neighbours' flag words to seq (peer_mode bit 0).
   // Bit 1 (option halo_sync = 2): the same workgroups — the only ones whose regions reach into the halo rows — poll
   // this slab's own flag words for wait_seq before they load (bounded, like halo_wait).  Everything that does not
-  // change from launch to launch sits in a device-resident MultiPeer: as kernel arguments those pointers stayed live in
-  // SGPRs to the end of the kernel, 92 instead of 76, which costs the 16x16 / 16x8 tiles their second workgroup per CU
-  // (more than 80 SGPRs admit 28 waves per CU, not 32: 384x384 4.54 instead of 3.46 us/step).
-  const struct MultiPeer *peer;
+  // change from launch to launch sits in the device-resident HaloPeer (384x384 ran 4.54 instead of 3.46 us/step with
+  // those pointers as kernel arguments).
+  const struct HaloPeer *peer;
   uint32_t seq, wait_seq;
   int peer_mode, peer_buf, edge_blocks;   // peer_buf: index of the destination grid (which of the neighbours' two grids)
 };
-
-struct MultiPeer {
-  float *push_lo[2], *push_hi[2];  // per grid: the south neighbour's top halo rows / the north neighbour's bottom halo rows
-  uint32_t *flag_lo, *flag_hi;     // the neighbours' flag words for pushes arriving from this slab
-  unsigned *ticket;
-  const uint32_t *wait_flags;      // this slab's own flag words
-  uint32_t *wait_err;
-  unsigned long long wait_ticks;
-  int push_rows;
-};
-
-// The kernel's own argument block, re-read where it is used: fields needed only at the very start or the very end of
-// a long kernel otherwise sit in SGPRs all the way through (the asm hides that this is the preloaded argument copy).
-template <class Args>
-__device__ __forceinline__ const Args *late_args() {
-  unsigned long long p = (unsigned long long)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
-  return reinterpret_cast<const Args *>(p);
-}
-
-// bounded spin of lanes 0 and 1 on the two flag words (see halo_wait)
-__device__ __forceinline__ void spin_on_flags(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
-  if (threadIdx.x < 2) {
-    const uint32_t *f = flags + threadIdx.x;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int32_t)(flag_load_system(f) - seq) < 0) {
-      __builtin_amdgcn_s_sleep(4);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
-        atomicOr(err, 1u);
-        break;
-      }
-    }
-  }
-}
-
-__global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
-  spin_on_flags(flags, seq, err, timeout);
-}
 
 // PEER: the compact launch-set form (three tile-row ranges, fused wait and push); a separate instantiation so that the
 // plain form keeps its 76-78 SGPRs
@@ -1415,7 +1582,7 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
   if constexpr (PEER) {
     const MultiArgs *la = late_args<MultiArgs>();
     if ((la->peer_mode & 2) && (int)blockIdx.x < la->edge_blocks) {
-      const MultiPeer *pp = la->peer;
+      const HaloPeer *pp = la->peer;
       spin_on_flags(pp->wait_flags, la->wait_seq, pp->wait_err, pp->wait_ticks);
       __syncthreads();
     }
@@ -1503,11 +1670,11 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
     const MultiArgs *la = late_args<MultiArgs>();
     const int edge_blocks = la->edge_blocks;
     if ((la->peer_mode & 1) && (int)blockIdx.x < edge_blocks) {
-      const MultiPeer *pp = la->peer;
+      const HaloPeer *pp = la->peer;
       const int fin = T & 1;
       constexpr int Q = kMultiTX / 4;
       const int push_rows = pp->push_rows;
-      float *const push_lo = pp->push_lo[la->peer_buf], *const push_hi = pp->push_hi[la->peer_buf];
+      float *const push_lo = pp->push[0][la->peer_buf & 1], *const push_hi = pp->push[1][la->peer_buf & 1];
       const int top0 = a.rows - push_rows;  // first owned row that goes north
       for (int i = tid; i < 9 * kMultiTY * Q; i += kMultiThreads) {
         const int k = i / (kMultiTY * Q), r = i - k * (kMultiTY * Q);

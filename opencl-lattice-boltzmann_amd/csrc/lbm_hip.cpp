@@ -181,7 +181,7 @@ struct Slab {
   // [1] by the north neighbour, [2] error bits of halo_wait, [3] ticket of halo_push
   uint32_t *halo_flags = nullptr;
   PeerLink south, north;
-  lbm::MultiPeer *d_peer = nullptr;   // device copy of what the fused push / wait of d2q9_multi needs (filled when the ring is connected)
+  lbm::HaloPeer *d_peer = nullptr;   // device copy of what the fused push / wait of d2q9_multi needs (filled when the ring is connected)
   double *av_tmp = nullptr;   // all-reduce target of the velocity record (rank mode), allocated on first use
   // output-stage scratch
   float *fin_partials = nullptr;
@@ -328,6 +328,17 @@ int multistep_effective(const lbm_ctx *c) {
   return ((long)c->p.nx * c->rows_min <= limit) ? cap : 0;
 }
 
+// Compact launch sets (peer transport): ONE launch per launch set on one stream — its first workgroups are the edge
+// tiles / edge chunks, which store the halo rows into the ring neighbours themselves and raise their flag words — instead
+// of edge launch + push kernel on an edge stream beside the interior launch.  For the LDS-tile kernel and for the
+// three- / four-step kernels in their default form (LDS windows, one row-set of loads in flight, plain loads).
+bool compact_sets(const lbm_ctx *c) {
+  if (!c->halo_mode || c->transport_eff != TRANSPORT_PEER || c->compact == 0) return false;
+  if (multistep_effective(c) > 0) return true;
+  const int lvl = fuse_level(c);
+  return (lvl == 3 || lvl == 4) && windows_in_lds(c) && step3_load_bufs(c) == 1 && c->nt_loads <= 0;
+}
+
 // Work decomposition of d2q9_step2 over stored rows [r0, r1): strips x chunks.  A unit's cost is
 // proportional to its rows + 2 and all units of a launch finish at about the same time, so equal chunks
 // leave the chip partly idle during the last round of units (17 % of the launch with 32-row chunks on
@@ -372,7 +383,11 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     // round costs more than it balances (1024x1024: 3-row chunks = 1720 units: 10.2 us/step; 2-row chunks =
     // 2560 units: 12.1; 4-row chunks = 1280 units: 11.6 — tools/ab_1024.py)
     const int one_round = (int)std::ceil(n / std::max(1.0, std::floor(slots)));
-    const bool single_round = one_round <= cmax;
+    // (one round only if the units really are resident at once: a pair schedule needs two slots per band and strip —
+    // with fewer, "one round" of 64-row chunks was 2192 units on 1500 free slots and the last workgroups started when the
+    // first had finished: compact 8192x1024 slab 212 instead of 220 GLUPS)
+    const bool fits = (double)waves_resident / g.nbands / s.strips >= (pairs ? 2.0 : 1.0);
+    const bool single_round = one_round <= cmax && fits;
     if (b == 0) g.single_round = single_round;
     while (rem > 0) {
       int sz = single_round ? std::max(2, one_round) : (int)std::ceil(rem / (2.0 * slots));
@@ -413,7 +428,7 @@ int fuse_schedule_pairs(const lbm_ctx *c, const Slab &s, int r0, int r1, int cma
   g.paired = false;
   // (not with row slabs: next to the edge launch's 20-KB workgroups and the RCCL kernel the 40-KB pairs of the interior
   // launch no longer all fit at once — 8192x1024 ring of one: 168 GLUPS paired, 232 unpaired, tools/ab_ring_pair.py)
-  if (kernel_can_pair && c->pair != 0 && !(c->halo_mode && c->pair < 0)) {
+  if (kernel_can_pair && c->pair != 0 && !(c->halo_mode && c->pair < 0 && !compact_sets(c))) {
     if (int rc = fuse_schedule(s, r0, r1, cmax, cmin, true, g, waves_per_simd, 2 * reserve, true)) return rc;
     if (g.single_round || c->pair > 0) {
       g.paired = true;
@@ -527,12 +542,17 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
         // in one round of equal units starves the edge workgroups that were not dispatched first until other EDGE
         // workgroups retire (kernel trace, 8192x1024 slab, d2q9_step4: edge kernel 140 us instead of 50, and with
         // the exchange behind it the critical path of the launch set)
-        const int rsv = 2 * n_edge_chunks * s.strips;  // the edge units that do work (skipped and empty chunks exit at once)
+        // (compact launch sets: the edge units are the first workgroups of the same launch and hold their slots — a pair
+        // workgroup both of its, also where one chunk of the pair is the skipped interior — until they are done)
+        const int rsv = compact_sets(c) ? 4 * n_edge_chunks * s.strips : 2 * n_edge_chunks * s.strips;  // the edge units that do work (skipped and empty chunks exit at once)
         if (int rc = fuse_schedule(s, i0, i1, cmax, cmin, true, s.f_main, 2, rsv)) return rc;
         if (int rc = fuse_schedule_pairs(c, s, i0, i1, c3max, c3min, s.f3_main, step3_sched_waves(c), rsv, step3_can_pair(c))) return rc;
         if (int rc = fuse_schedule_pairs(c, s, i0, i1, c4max, c4min, s.f4_main, step4_sched_waves(c), rsv, windows_in_lds(c))) return rc;
       } else {
+        // no interior: the edge chunks are the whole slab (the launch form — pair kernel or not — is still taken from
+        // these schedules)
         s.f_main.units = s.f3_main.units = s.f4_main.units = 0;
+        s.f_main.paired = s.f3_main.paired = s.f4_main.paired = false;
       }
       s.nb_total = std::max(s.nb_total, std::max(s.f_main.units, std::max(s.f3_main.units, s.f4_main.units)) + e.units);
     } else {
@@ -681,6 +701,21 @@ void launch_step4(const lbm_ctx *c, const Step2Args &a0, float *partials3, float
   hipLaunchKernelGGL((d2q9_step4<true, 0>), dim3(units), dim3(64), 0, st, a0, partials3, partials4);
 }
 
+// compact launch set of the three- / four-step kernels: edge units first, then the interior units, one launch
+void launch_compact(int level, bool paired, const Step2Args &a0, float *partials3, float *partials4, int main_units, hipStream_t st) {
+  Step2Args a = a0;
+  if (paired) {
+    a.units_per_band = a0.units_per_band / 2;  // chunk pairs x strips
+    const dim3 grid((a0.edge_units + main_units) / 2), block(128);
+    if (level == 4) hipLaunchKernelGGL((d2q9_step4p<true, 0, true>), grid, block, 0, st, a, partials3, partials4);
+    else hipLaunchKernelGGL((d2q9_step3p<true, 0, true>), grid, block, 0, st, a, partials3);
+    return;
+  }
+  const dim3 grid(a0.edge_units + main_units), block(64);
+  if (level == 4) hipLaunchKernelGGL((d2q9_step4<true, 0, true>), grid, block, 0, st, a, partials3, partials4);
+  else hipLaunchKernelGGL((d2q9_step3<true, 0, true, 1, true>), grid, block, 0, st, a, partials3);
+}
+
 MultiArgs base_args_multi(const lbm_ctx *c, const Slab &s, int src, int T, bool accel_next) {
   MultiArgs a{};
   a.src = s.cells[src];
@@ -756,10 +791,6 @@ int wait_halos(lbm_ctx *c, Slab &s, hipStream_t st, uint32_t seq) {
     HIP_TRY(hipGetLastError());
   }
   return LBM_OK;
-}
-
-bool compact_sets(const lbm_ctx *c) {
-  return c->halo_mode && c->transport_eff == TRANSPORT_PEER && c->compact != 0 && multistep_effective(c) > 0;
 }
 
 // Slab mode: move the `halo_depth` bottom and top owned rows of grid `buf` into the ring neighbours' halo
@@ -1006,16 +1037,49 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         if (int rc = mark(s, 4, s.s_main)) return rc;
         continue;
       }
+      if (compact && (kind == KIND_FUSED4 || kind == KIND_FUSED3)) {
+        // ---- compact launch set of the window kernels: wait for the neighbours' rows of the latest exchange, then ONE
+        // launch — the edge chunks first (they push this set's halo rows and raise the flags), then the interior chunks
+        if (int rc = wait_halos(c, s, s.s_main, c->halo_seq)) return rc;
+        const int level = kind == KIND_FUSED4 ? 4 : 3;
+        const FuseGeom &g = level == 4 ? s.f4_main : s.f3_main;
+        Step2Args a = base_args2(c, s, src, !last, g);
+        a.partials1 = slot1;
+        a.partials2 = slot2;
+        float *slot3 = slot2 + s.nb_total, *slot4 = slot3 + s.nb_total;
+        a.edge_chunk_start = s.f_edge.chunk_start;
+        a.edge_nchunks = s.f_edge.nchunks;
+        a.edge_units = s.f_edge.units;
+        a.edge_skip = s.f_edge.skip;
+        a.edge_partial_off = g.units;
+        a.peer = s.d_peer;
+        if (!last) {
+          a.peer_mode = 1;
+          a.peer_buf = src ^ 1;
+          a.seq = c->halo_seq + 1;
+        }
+        if (int rc = mark(s, 3, s.s_main)) return rc;
+        launch_compact(level, g.paired, a, slot3, slot4, g.units, s.s_main);
+        HIP_TRY(hipGetLastError());
+        if (int rc = mark(s, 4, s.s_main)) return rc;
+        continue;
+      }
       // ---- slab mode: edge rows first (they feed the neighbours), interior meanwhile ----
+      // (a compact run gets here with the leftover steps at its end only: no exchange follows, both launches go to
+      // the main stream one after the other)
+      const hipStream_t s_edge = compact ? s.s_main : s.s_edge;
       // edge launch: needs the previous set's halos (edge stream order; with the peer transport the neighbours'
       // pushes of the latest exchange, announced in this slab's flag words) and interior (event)
       if (c->transport_eff == TRANSPORT_PEER)
-        if (int rc = wait_halos(c, s, s.s_edge, c->halo_seq)) return rc;
-      HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
-      // interior launch: needs the previous set's edge rows
-      HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
-      if (int rc = mark(s, 0, s.s_edge)) return rc;
-      if (int rc = mark(s, 3, s.s_main)) return rc;
+        if (int rc = wait_halos(c, s, s_edge, c->halo_seq)) return rc;
+      if (!compact) {
+        HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
+        // interior launch: needs the previous set's edge rows
+        HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
+      }
+      if (int rc = mark(s, 0, s_edge)) return rc;
+      if (!compact)
+        if (int rc = mark(s, 3, s.s_main)) return rc;
       if (kind == KIND_MULTI) {
         // edge = the tile rows that hold the halo_depth bottom and top rows (what the neighbours receive):
         // tile row 0 and the tile rows from t_top up; interior = tile rows 1 .. t_top-1
@@ -1025,7 +1089,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         MultiArgs e = base_args_multi(c, s, src, adv, !last);
         e.partials = slot1 + (size_t)int_trows * s.m_tiles_x;
         e.ty_begin = 0; e.ty_split = 1; e.ty_begin2 = t_top;
-        launch_multi(s, e, edge_trows, s.s_edge);
+        launch_multi(s, e, edge_trows, s_edge);
         HIP_TRY(hipGetLastError());
         if (int_trows > 0) {
           MultiArgs mm = base_args_multi(c, s, src, adv, !last);
@@ -1040,7 +1104,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         e.skip_chunk = s.f_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
         e.partials1 = slot1 + s.f4_main.units;
         e.partials2 = slot2 + s.f4_main.units;
-        launch_step4(c, e, slot3 + s.f4_main.units, slot4 + s.f4_main.units, s.f_edge.units, s.s_edge, s.f4_main.paired);
+        launch_step4(c, e, slot3 + s.f4_main.units, slot4 + s.f4_main.units, s.f_edge.units, s_edge, s.f4_main.paired);
         HIP_TRY(hipGetLastError());
         if (s.f4_main.units > 0) {
           Step2Args m = base_args2(c, s, src, !last, s.f4_main);
@@ -1055,7 +1119,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         e.skip_chunk = s.f_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
         e.partials1 = slot1 + s.f3_main.units;
         e.partials2 = slot2 + s.f3_main.units;
-        launch_step3(c, e, slot3 + s.f3_main.units, s.f_edge.units, s.s_edge, s.f3_main.paired);
+        launch_step3(c, e, slot3 + s.f3_main.units, s.f_edge.units, s_edge, s.f3_main.paired);
         HIP_TRY(hipGetLastError());
         if (s.f3_main.units > 0) {
           Step2Args m = base_args2(c, s, src, !last, s.f3_main);
@@ -1069,7 +1133,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         e.skip_chunk = s.f_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
         e.partials1 = slot1 + s.f_main.units;
         e.partials2 = slot2 + s.f_main.units;
-        launch_step2(c, e, s.f_edge.units, s.s_edge);
+        launch_step2(c, e, s.f_edge.units, s_edge);
         HIP_TRY(hipGetLastError());
         if (s.f_main.units > 0) {
           Step2Args m = base_args2(c, s, src, !last, s.f_main);
@@ -1082,7 +1146,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         StepArgs e = base_args(c, s, src, !last);
         e.y_begin = s.row0; e.y_count = 2 * s.edge_rows; e.y_split = s.edge_rows; e.y_begin2 = s.row0 + s.rows - s.edge_rows;
         e.partials = slot1 + s.nb_main;
-        launch_step(c, e, s.nb_edge, s.s_edge);
+        launch_step(c, e, s.nb_edge, s_edge);
         HIP_TRY(hipGetLastError());
         if (s.rows > 2 * s.edge_rows) {
           StepArgs m = base_args(c, s, src, !last);
@@ -1094,13 +1158,15 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           HIP_TRY(hipMemsetAsync(slot1, 0, sizeof(float) * s.nb_main, s.s_main));
         }
       }
-      HIP_TRY(hipEventRecord(s.ev_edgek[q], s.s_edge));
-      HIP_TRY(hipEventRecord(s.ev_main[q], s.s_main));
-      if (int rc = mark(s, 1, s.s_edge)) return rc;
+      if (!compact) {
+        HIP_TRY(hipEventRecord(s.ev_edgek[q], s.s_edge));
+        HIP_TRY(hipEventRecord(s.ev_main[q], s.s_main));
+      }
+      if (int rc = mark(s, 1, s_edge)) return rc;
       if (int rc = mark(s, 4, s.s_main)) return rc;
     }
-    if (multi && compact && kind == KIND_MULTI) {
-      if (!last) c->halo_seq++;     // the edge tiles of this set's launches have pushed exchange number halo_seq
+    if (multi && compact && (kind == KIND_MULTI || kind == KIND_FUSED3 || kind == KIND_FUSED4)) {
+      if (!last) c->halo_seq++;     // the edge units of this set's launches have pushed exchange number halo_seq
     } else if (multi) {
       if (!last)
         if (int rc = exchange_halos(c, src ^ 1, q, compact)) return rc;
@@ -1144,6 +1210,7 @@ int sync_all(lbm_ctx *c) {
       HIP_TRY(hipMemcpy(&err, s.halo_flags + 2, sizeof err, hipMemcpyDeviceToHost));
       if (err) {
         c->failed = true;
+        if (err & 2u) return fail(LBM_ERR_COMM, "peer transport: slab %d computed a halo row outside its edge rows (internal error)", s.index);
         return fail(LBM_ERR_COMM, "peer transport: slab %d waited %d s for a neighbour's halo rows that never came", s.index,
                     (int)(kHaloWaitTicks / 100000000ull));
       }
@@ -1363,10 +1430,10 @@ int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *whi
 
 // device-side description of a connected slab's neighbours for the fused push / wait of d2q9_multi
 int upload_multi_peer(Slab &s) {
-  MultiPeer h{};
+  HaloPeer h{};
   for (int b = 0; b < 2; b++) {
-    h.push_lo[b] = s.south.cells[b] + (size_t)(s.row0 + s.south.rows) * s.row_stride;
-    h.push_hi[b] = s.north.cells[b];
+    h.push[0][b] = s.south.cells[b] + (size_t)(s.row0 + s.south.rows) * s.row_stride;
+    h.push[1][b] = s.north.cells[b];
   }
   h.flag_lo = s.south.flags + 1;  // this slab is the south neighbour's NORTH neighbour
   h.flag_hi = s.north.flags + 0;
@@ -1375,6 +1442,8 @@ int upload_multi_peer(Slab &s) {
   h.wait_err = s.halo_flags + 2;
   h.wait_ticks = kHaloWaitTicks;
   h.push_rows = s.row0;
+  h.row_lo0 = s.row0;      // bottom edge rows [row0, 2 row0) -> the south neighbour's top halo rows
+  h.row_hi0 = s.rows;      // top edge rows [rows, rows + row0) -> the north neighbour's bottom halo rows
   if (set_dev(s)) return LBM_ERR_HIP;
   if (!s.d_peer && dev_alloc(&s.d_peer, 1)) return LBM_ERR_HIP;
   HIP_TRY(hipMemcpy(s.d_peer, &h, sizeof h, hipMemcpyHostToDevice));
@@ -1459,7 +1528,7 @@ int lbm_connect_peers(lbm_ctx *c, const void *south_info, const void *north_info
   s.north = north;
   if (int rc = upload_multi_peer(s)) return rc;
   c->transport_eff = TRANSPORT_PEER;
-  return LBM_OK;
+  return rebuild_geometry(c);
 }
 
 const char *lbm_last_error(void) { return g_err.c_str(); }
@@ -1578,6 +1647,8 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
       c->transport_eff = TRANSPORT_PEER;
     }
   }
+  // the chunk schedules depend on the transport (compact launch sets reserve nothing for an edge launch and may pair)
+  if (rc == LBM_OK && c->halo_mode) rc = rebuild_geometry(c);
   if (rc == LBM_OK) {
     c->av_host = (double *)malloc(sizeof(double) * (size_t)std::max(1, params->max_iters));
     if (!c->av_host) rc = fail(LBM_ERR_ARG, "out of host memory");
@@ -1855,12 +1926,12 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   if (!strcmp(key, "nt_loads")) {
     if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "nt_loads must be -1 (auto), 0, 1 or 2");
     c->nt_loads = (int)value;
-    return LBM_OK;
+    return c->halo_mode ? rebuild_geometry(c) : LBM_OK;   // (whether launch sets are compact depends on it)
   }
   if (!strcmp(key, "fuse")) {
     if (value < -1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be -1 (auto), 0, 1 (or 2), 3 or 4");
     c->fuse = (int)value;
-    return LBM_OK;
+    return c->halo_mode ? rebuild_geometry(c) : LBM_OK;
   }
   if (!strcmp(key, "tile_shape")) {
     if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "tile_shape must be -1..2");
@@ -1893,13 +1964,13 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
       return fail(LBM_ERR_ARG, "transport must be 1 (RCCL send/recv) or 3 (peer stores)");
     }
     c->transport_eff = (int)value;
-    return LBM_OK;
+    return rebuild_geometry(c);
   }
   if (!strcmp(key, "compact")) {
     if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "compact must be -1 (auto), 0 or 1");
     if (int rc = sync_all(c)) return rc;
     c->compact = (int)value;
-    return LBM_OK;
+    return rebuild_geometry(c);
   }
   if (!strcmp(key, "halo_sync")) {
     if (value < 0 || value > 2)
@@ -1918,7 +1989,7 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   if (!strcmp(key, "multistep")) {
     if (value < -1 || value > kMultiMaxT) return fail(LBM_ERR_ARG, "multistep must be -1..%d", kMultiMaxT);
     c->multistep = (int)value;
-    return LBM_OK;
+    return c->halo_mode ? rebuild_geometry(c) : LBM_OK;
   }
   if (!strcmp(key, "vec")) {
     // cells per thread of the single-step kernel: 4 (float4 rows) or 1

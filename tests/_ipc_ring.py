@@ -64,7 +64,9 @@ def main():
             one.upload(cells0)
             one.run(nsteps)
             ref, av_ref = one.download()
-        assert np.array_equal(part.numpy(), ref), "assembled state differs from the single-slab run"
+        if not np.array_equal(part.numpy(), ref):
+            bad = np.argwhere(np.any(part.numpy() != ref, axis=(0, 2))).ravel()
+            raise AssertionError("assembled state differs from the single-slab run in %d rows: %s" % (bad.size, bad))
         assert np.max(np.abs(avt.numpy() - av_ref) / av_ref) < 2e-6
         print("ipc-ring ok: %d processes, %dx%d, %d steps, fuse %d multistep %d sync %d" % (world, nx, ny, nsteps, fuse, multistep, sync))
     dist.barrier()
