@@ -161,7 +161,7 @@ __device__ __forceinline__ void block_store_partial(float v, float *partials) {
 }
 
 // gathered distributions g[k][v] -> collided cell values o[k][v]; returns the sum of |j|/rho of the 4 cells
-// (tried and rejected, tools/ab_step3.py: bounce-back as a wave-uniform fix-up branch after an obstacle-free
+// (tried and rejected, tools/ab.py: bounce-back as a wave-uniform fix-up branch after an obstacle-free
 // collision — 14 % slower in d2q9_step3, 4-40 % slower in d2q9_step2: both g and o stay live across the branch)
 __device__ __forceinline__ float collide4(const float (&g)[9][4], uint32_t m, float omega, bool accel, float aw1, float aw2,
                                           float (&o)[9][4]) {
@@ -645,7 +645,7 @@ __device__ __forceinline__ void issue_row_loads(const Step2Args &a, int r, int x
 
 // The same loads written as (wave-uniform row pointer) + (32-bit unsigned byte offset of the lane): the shape the
 // SGPR-base addressing mode of global_load takes — no 64-bit vector address per access, six VGPRs fewer.  Worth
-// nothing in d2q9_step3 (tools/ab_step3.py), but d2q9_step4 sits at the 256-register limit, where every register
+// nothing in d2q9_step3 (tools/ab.py), but d2q9_step4 sits at the 256-register limit, where every register
 // that is not spilled counts.
 __device__ __forceinline__ const float *at_byte(const float *uniform_base, unsigned byte_off) {
   return reinterpret_cast<const float *>(reinterpret_cast<const char *>(uniform_base) + byte_off);

@@ -277,7 +277,7 @@ bool step3_can_pair(const lbm_ctx *c) { return windows_in_lds(c) && step3_load_b
 
 // waves per SIMD the d2q9_step3 schedule plans for: two with the windows in LDS.  (The unpaired kernel did better with
 // one round of 1024 longer units on grids of up to 800K cells — 1024x512 81 / 93 GLUPS planned for 2 / 1, 768x768 90 /
-// 102; with chunk pairs, d2q9_step3p, two waves per SIMD win everywhere: 98 and 107, tools/ab_pair.py.)
+// 102; with chunk pairs, d2q9_step3p, two waves per SIMD win everywhere: 98 and 107, tools/ab.py.)
 int step3_sched_waves(const lbm_ctx *c) {
   if (c->sched_waves > 0) return c->sched_waves;
   if (!windows_in_lds(c)) return 1;
@@ -298,10 +298,10 @@ int fuse_level(const lbm_ctx *c) {
   if (c->fuse >= 0) {
     lvl = c->fuse == 0 ? 0 : (c->fuse >= 3 ? c->fuse : 2);
   } else {
-    // auto (same-box A/B, tools/ab_mid.py + tools/ab_fuse3.py, GLUPS two-step / three-step): the smallest grids go
+    // auto (same-box A/B, tools/ab.py + tools/ab.py, GLUPS two-step / three-step): the smallest grids go
     // to the LDS tile kernel (multistep_effective); 768x512 89 / 86 -> two steps per launch; 1024x512 82 / 93,
     // 768x768 89 / 102, 1024x768 106 / 112, 1024x1024 114 / 119, 1536x1024 127 / 147 -> three steps per launch
-    // ... and four steps per launch from 1.25M cells up (tools/ab_pair4.py, three / four steps, chunk pairs where the
+    // ... and four steps per launch from 1.25M cells up (tools/ab.py, three / four steps, chunk pairs where the
     // launch is one round: 1024x768 129 / 128, 1024x1024 143 / 136, 1536x1024 162 / 175, 2048x1024 170 / 192,
     // 2048x2048 183 / 223, 4096x4096 217 / 273, 8192x8192 230 / 295)
     const long cells = (long)c->p.nx * c->rows_min;
@@ -381,7 +381,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     // a grid small enough to be done in ONE round of units (all of them resident at once) gets equal chunks
     // that just fill the wave slots: every extra unit costs two redundant rows, and a second, partly filled
     // round costs more than it balances (1024x1024: 3-row chunks = 1720 units: 10.2 us/step; 2-row chunks =
-    // 2560 units: 12.1; 4-row chunks = 1280 units: 11.6 — tools/ab_1024.py)
+    // 2560 units: 12.1; 4-row chunks = 1280 units: 11.6 — tools/ab.py)
     const int one_round = (int)std::ceil(n / std::max(1.0, std::floor(slots)));
     // (one round only if the units really are resident at once: a pair schedule needs two slots per band and strip —
     // with fewer, "one round" of 64-row chunks was 2192 units on 1500 free slots and the last workgroups started when the
@@ -420,14 +420,14 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
 }
 
 // Schedule for a kernel that has a chunk-pair form.  Pairs pay off where chunks are short, i.e. in one-round schedules
-// (tools/ab_pair4.py, unpaired / paired GLUPS: 1024x1024 117 / 143, 2048x1024 165 / 192, 2048x2048 211 / 223,
+// (tools/ab.py, unpaired / paired GLUPS: 1024x1024 117 / 143, 2048x1024 165 / 192, 2048x2048 211 / 223,
 // 4096x4096 268 / 273); with the long chunks of multi-round schedules the two waves of a workgroup only hold each
 // other's LDS (8192x8192 295 / 289).  c->pair: -1 = that rule, 1 = always, 0 = never.
 int fuse_schedule_pairs(const lbm_ctx *c, const Slab &s, int r0, int r1, int cmax, int cmin, FuseGeom &g, int waves_per_simd,
                         int reserve, bool kernel_can_pair) {
   g.paired = false;
   // (not with row slabs: next to the edge launch's 20-KB workgroups and the RCCL kernel the 40-KB pairs of the interior
-  // launch no longer all fit at once — 8192x1024 ring of one: 168 GLUPS paired, 232 unpaired, tools/ab_ring_pair.py)
+  // launch no longer all fit at once — 8192x1024 ring of one: 168 GLUPS paired, 232 unpaired, tools/ab.py)
   if (kernel_can_pair && c->pair != 0 && !(c->halo_mode && c->pair < 0 && !compact_sets(c))) {
     if (int rc = fuse_schedule(s, r0, r1, cmax, cmin, true, g, waves_per_simd, 2 * reserve, true)) return rc;
     if (g.single_round || c->pair > 0) {
@@ -483,7 +483,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     // x decomposition: lanes 0 and 63 of a wave are halo lanes, so a strip has at most 62 output lanes — but
     // strips must start on 64-byte boundaries (multiples of 4 lanes): with 61-lane strips (976 B) the stores of
     // neighbouring strips split 64-B DRAM bursts and the kernel ran 9 % slower (147.8 vs 162.1 GLUPS on 8192x8192,
-    // tools/ab_lanes.py) although 60-lane strips leave more lanes idle
+    // tools/ab.py) although 60-lane strips leave more lanes idle
     s.strips = div_up(q4, 60);
     s.lanes_out = std::min(60, (div_up(q4, s.strips) + 3) / 4 * 4);
     if (g_defaults.lanes_out > 0) {  // lbm_set_default("lanes_out"): output lanes per strip (validated 4..62)
@@ -497,14 +497,14 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     cmax = std::max(2, std::min(cmax, s.rows));
     const int cmin = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (big ? 2 : 4), cmax));
     // d2q9_step3: six redundant intermediate rows per chunk.  With the windows in LDS (two waves per SIMD) the
-    // schedule is flat between 8/4 and 32/6 (tools/ab_fuse3.py, 8192x8192: 32/6 226, 16/6 229, 8/4 230, 6/2 224,
+    // schedule is flat between 8/4 and 32/6 (tools/ab.py, 8192x8192: 32/6 226, 16/6 229, 8/4 230, 6/2 224,
     // 4/2 211 GLUPS; 4096x4096: 32/6 215, 16/6 213, 8/4 212; 8192x1024: 32/6 195, 16/6 201, 8/2 190); with register
     // windows (one wave per SIMD) long chunks: 8192x8192 16/6 178, 32/6 186, 64/8 188
     const bool w_lds = windows_in_lds(c);
     int c3max = c->chunk_rows > 0 ? c->chunk_rows : (w_lds ? 16 : (c->rows_min >= 2048 ? 64 : 32));
     c3max = std::max(4, std::min(c3max, s.rows));
     const int c3min = std::max(2, std::min(c->chunk_min > 0 ? c->chunk_min : (!w_lds && c->rows_min >= 2048 ? 8 : 6), c3max));
-    // d2q9_step4: twelve redundant intermediate rows per chunk -> longer chunks (tools/ab_step4d.py, chunks 16/6,
+    // d2q9_step4: twelve redundant intermediate rows per chunk -> longer chunks (tools/ab.py, chunks 16/6,
     // 32/8, 64/16, 128/32: 8192x8192 288 / 299 / 298 / 295 GLUPS, 4096x4096 247 / 252 / 275 / 275, 8192x1024
     // 223 / 246 / 246 / 246)
     const int c4max = std::max(4, std::min(c->chunk_rows > 0 ? c->chunk_rows : 64, s.rows));
@@ -517,7 +517,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       // edge schedule: chunk table {bottom edge rows, interior, top edge rows}; the launch skips the interior chunk.
       // One chunk per edge.  Splitting an edge into single-row chunks (a round-1 experiment) shortens the edge
       // kernel of d2q9_step3 from 47 to 32 us (5 instead of 7 iterations per wave) but did not shorten the launch set:
-      // 8192x1024 ring of one 45.5 -> 47.0 us/step, 4096x512 18.3 -> 17.0, 2048x256 9.1 -> 9.3 (tools/ab_edge.sh)
+      // 8192x1024 ring of one 45.5 -> 47.0 us/step, 4096x512 18.3 -> 17.0, 2048x256 9.1 -> 9.3 (tools/ab.py)
       const int ec = s.edge_rows;
       std::vector<int> tab;
       for (int y = 0; y < s.edge_rows; y += ec) tab.push_back(s.row0 + y);
@@ -677,7 +677,7 @@ void launch_step3(const lbm_ctx *c, const Step2Args &a0, float *partials3, int u
   const Step2Args &a = a0;
   // source loads: with two waves per SIMD (LDS windows) plain loads win at every size — 8192x8192 227.6 against 221.4
   // GLUPS with the hybrid scheme, 202.3 all non-temporal; 2048x2048 180.8 / 175.2 / 165.3; 1024x1024 117.9 / 116.4 /
-  // 106.0 (tools/ab_mid4.py) — the rows a chunk shares with its neighbours and the strips' edge lines stay in L2;
+  // 106.0 (tools/ab.py) — the rows a chunk shares with its neighbours and the strips' edge lines stay in L2;
   // with one wave per SIMD (register windows) the lower latency of the hybrid scheme was worth more
   const int ntl = c->nt_loads >= 0 ? c->nt_loads : (lds ? 0 : 2);
   const bool one = step3_load_bufs(c) == 1;
@@ -757,7 +757,7 @@ void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t s
   // non-temporal (lower latency, no cache pollution) for the rows only this chunk reads, plain for the two
   // intermediate rows at either end of the chunk, whose source rows the neighbouring chunk reads at the same
   // time and should find in L2.  All-nt loads lose that reuse (PMC on 8192x8192: 5.90 GB per launch instead
-  // of 5.13 GB).  Same-box A/B (tools/ab_head.py), plain / all-nt / hybrid in GLUPS: 8192x8192 136 / 140 / 153,
+  // of 5.13 GB).  Same-box A/B (tools/ab.py), plain / all-nt / hybrid in GLUPS: 8192x8192 136 / 140 / 153,
   // 4096x4096 126 / 133 / 147, 2048x2048 110 / 117 / 128, 1024x1024 82 / 102 / 113.
   const bool nts = c->nt_stores >= 0 ? c->nt_stores != 0 : true;
   const int ntl = c->nt_loads >= 0 ? c->nt_loads : (nts ? 2 : 0);
