@@ -195,8 +195,8 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "transport"    halo transport of a context that carries halo rows: 1 = RCCL send/recv (needs a communicator),
  *                  3 = peer stores (needs connected peers); read-only values 2 = device-to-device copies, 0 = none yet
  *   "halo_sync"    peer transport, consumer side: 0 = wait kernel with a bounded spin (default), 1 = hipStreamWaitValue32,
- *                  2 = the edge tiles of the consuming launch poll the flag words themselves (compact launch sets only,
- *                  elsewhere like 0)
+ *                  2 = the edge tiles / edge chunks of the consuming launch poll the flag words themselves (compact
+ *                  launch sets only, elsewhere like 0)
  *   "compact"      peer transport + LDS-tile kernel (small slabs): -1/1 = one launch per launch set on one stream, the
  *                  edge tiles store the halo rows into the neighbours themselves; 0 = edge launch / interior launch /
  *                  push kernel on two streams like the larger slabs

@@ -469,19 +469,20 @@ __device__ __forceinline__ const Args *late_args() {
   return reinterpret_cast<const Args *>(p);
 }
 
-// bounded spin of lanes 0 and 1 on the two flag words (see halo_wait)
-__device__ __forceinline__ void spin_on_flags(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
-  if (threadIdx.x < 2) {
-    const uint32_t *f = flags + threadIdx.x;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int32_t)(flag_load_system(f) - seq) < 0) {
-      __builtin_amdgcn_s_sleep(4);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
-        atomicOr(err, 1u);
-        break;
-      }
+// bounded spin on one flag word: gives up after `timeout` ticks of s_memrealtime (100 MHz) and raises the error word
+__device__ __forceinline__ void spin_on_flag(const uint32_t *f, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((int32_t)(flag_load_system(f) - seq) < 0) {
+    __builtin_amdgcn_s_sleep(4);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
+      atomicOr(err, 1u);
+      break;
     }
   }
+}
+// lanes 0 and 1 of a workgroup on the slab's two flag words (see halo_wait)
+__device__ __forceinline__ void spin_on_flags(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+  if (threadIdx.x < 2) spin_on_flag(flags + threadIdx.x, seq, err, timeout);
 }
 
 __global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
@@ -538,7 +539,8 @@ struct Step2Args {
   int edge_nchunks, edge_units, edge_skip;
   int edge_partial_off;          // edge unit u keeps its velocity sums in slot edge_partial_off + u
   const struct HaloPeer *peer;
-  uint32_t seq;
+  uint32_t seq, wait_seq;        // peer_mode bit 1 (option halo_sync = 2): the edge waves — the only readers of halo rows —
+                                 // poll the slab's own flag words for wait_seq before their first load (bounded spin)
   int peer_mode, peer_buf;       // peer_buf: which of the neighbours' two grids the pushed rows go to
 };
 
@@ -943,6 +945,14 @@ __global__ __launch_bounds__(64) void d2q9_step3(const Step2Args a, float *parti
   // decided once (re-reading it from the argument block in every row iteration drained the wave's loads each time:
   // 8192x4096 slab 246 instead of 281 GLUPS)
   const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  if constexpr (PUSH) {
+    // in-kernel wait for the neighbours' halo rows (halo_sync = 2): every edge wave for itself, before its first load
+    if (us.edge && (a.peer_mode & 2)) {
+      const Step2Args *la = late_args<Step2Args>();
+      const HaloPeer *pp = la->peer;
+      if ((threadIdx.x & 63) < 2) spin_on_flag(pp->wait_flags + (threadIdx.x & 63), la->wait_seq, pp->wait_err, pp->wait_ticks);
+    }
+  }
   const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
   if (slot >= us.units_per_band) return;
   const int unit0 = band * us.units_per_band + slot;
@@ -1096,6 +1106,14 @@ __global__ __launch_bounds__(128) void d2q9_step3p(const Step2Args a, float *par
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const UnitSel us = select_unit<PUSH>(a, a.edge_units / 2);
   const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  if constexpr (PUSH) {
+    // in-kernel wait for the neighbours' halo rows (halo_sync = 2): every edge wave for itself, before its first load
+    if (us.edge && (a.peer_mode & 2)) {
+      const Step2Args *la = late_args<Step2Args>();
+      const HaloPeer *pp = la->peer;
+      if ((threadIdx.x & 63) < 2) spin_on_flag(pp->wait_flags + (threadIdx.x & 63), la->wait_seq, pp->wait_err, pp->wait_ticks);
+    }
+  }
   const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
   if (slot >= us.units_per_band) return;  // units_per_band counts chunk PAIRS x strips here
   const int punit = band * us.units_per_band + slot;
@@ -1222,6 +1240,14 @@ __global__ __launch_bounds__(64, 2) void d2q9_step4(const Step2Args a, float *pa
   // decided once (re-reading it from the argument block in every row iteration drained the wave's loads each time:
   // 8192x4096 slab 246 instead of 281 GLUPS)
   const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  if constexpr (PUSH) {
+    // in-kernel wait for the neighbours' halo rows (halo_sync = 2): every edge wave for itself, before its first load
+    if (us.edge && (a.peer_mode & 2)) {
+      const Step2Args *la = late_args<Step2Args>();
+      const HaloPeer *pp = la->peer;
+      if ((threadIdx.x & 63) < 2) spin_on_flag(pp->wait_flags + (threadIdx.x & 63), la->wait_seq, pp->wait_err, pp->wait_ticks);
+    }
+  }
   const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
   if (slot >= us.units_per_band) return;
   const int unit0 = band * us.units_per_band + slot;
@@ -1351,6 +1377,14 @@ __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const UnitSel us = select_unit<PUSH>(a, a.edge_units / 2);
   const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  if constexpr (PUSH) {
+    // in-kernel wait for the neighbours' halo rows (halo_sync = 2): every edge wave for itself, before its first load
+    if (us.edge && (a.peer_mode & 2)) {
+      const Step2Args *la = late_args<Step2Args>();
+      const HaloPeer *pp = la->peer;
+      if ((threadIdx.x & 63) < 2) spin_on_flag(pp->wait_flags + (threadIdx.x & 63), la->wait_seq, pp->wait_err, pp->wait_ticks);
+    }
+  }
   const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
   if (slot >= us.units_per_band) return;  // units_per_band counts chunk PAIRS x strips here
   const int punit = band * us.units_per_band + slot;

@@ -781,8 +781,8 @@ struct RcclTransport {
 
 // PEER transport, consumer side: the launch that follows on `st` reads halo rows that exchange number `seq` fills
 int wait_halos(lbm_ctx *c, Slab &s, hipStream_t st, uint32_t seq) {
-  // (halo_sync 2 — the wait inside the consuming kernel — exists for the compact launch sets of d2q9_multi only;
-  // every other launch is ordered behind the wait kernel)
+  // (halo_sync 2 — the wait inside the consuming kernel — exists for compact launch sets; every other launch is
+  // ordered behind the wait kernel)
   if (c->halo_sync == 1) {
     HIP_TRY(hipStreamWaitValue32(st, s.halo_flags, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
     HIP_TRY(hipStreamWaitValue32(st, s.halo_flags + 1, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
@@ -1040,7 +1040,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (compact && (kind == KIND_FUSED4 || kind == KIND_FUSED3)) {
         // ---- compact launch set of the window kernels: wait for the neighbours' rows of the latest exchange, then ONE
         // launch — the edge chunks first (they push this set's halo rows and raise the flags), then the interior chunks
-        if (int rc = wait_halos(c, s, s.s_main, c->halo_seq)) return rc;
+        if (c->halo_sync != 2)
+          if (int rc = wait_halos(c, s, s.s_main, c->halo_seq)) return rc;
         const int level = kind == KIND_FUSED4 ? 4 : 3;
         const FuseGeom &g = level == 4 ? s.f4_main : s.f3_main;
         Step2Args a = base_args2(c, s, src, !last, g);
@@ -1053,8 +1054,12 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         a.edge_skip = s.f_edge.skip;
         a.edge_partial_off = g.units;
         a.peer = s.d_peer;
+        if (c->halo_sync == 2) {
+          a.peer_mode |= 2;
+          a.wait_seq = c->halo_seq;
+        }
         if (!last) {
-          a.peer_mode = 1;
+          a.peer_mode |= 1;
           a.peer_buf = src ^ 1;
           a.seq = c->halo_seq + 1;
         }

@@ -307,7 +307,8 @@ def test_transport_self_ring(transport):
 
 @pytest.mark.parametrize("world,nx,ny,nsteps,fuse,multistep,sync", [(2, 512, 96, 23, 3, 0, 0), (3, 256, 150, 29, 0, 8, 0),
                                                                    (4, 2048, 64, 14, 4, 0, 1), (2, 256, 24, 11, 0, 0, 1),
-                                                                   (4, 1024, 256, 203, 0, 8, 2), (2, 300, 40, 37, 0, 5, 2)])
+                                                                   (4, 1024, 256, 203, 0, 8, 2), (2, 300, 40, 37, 0, 5, 2),
+                                                                   (4, 2048, 256, 30, 4, 0, 2), (3, 1024, 300, 25, 3, 0, 2)])
 def test_peer_transport_between_processes(world, nx, ny, nsteps, fuse, multistep, sync):
     """the peer transport across PROCESS boundaries: `world` processes share the one GPU, each owns a row slab, maps
     its neighbours' grids and flag words through HIP IPC, pushes its edge rows into them and waits on its own flags
@@ -642,6 +643,8 @@ def test_bench_one_process_per_gpu_path_single_rank():
     assert pr[0]["transport"] == j["transport"] and (pr[0]["edge_us"] > 0) == (j["transport"] == "rccl")
     # and the reference's 1024x1024 input row-partitioned over the same ranks (BASELINE config 4's leg of a multi-GPU record)
     assert j["also"]["value"] > 1000 and j["also"]["halo_depth"] >= 3 and len(j["also"]["per_rank_launch_set_us"]) == 1
+    # 600 steps from rest with each transport gave the same av_vels record (a transport delivering stale halo rows would not)
+    assert j["also"]["transport_cross_check"] == "ok" and "transport_rejected" not in j
 
 
 def test_abi_error_behaviour(lbm):
