@@ -36,7 +36,10 @@ BYTES_PER_LU = 72.0       # algorithmic: 9 fp32 loads + 9 fp32 stores per lattic
 MASK_BYTES = 1.0          # obstacle mask, one byte per cell and launch
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 KERNELS = {0: "d2q9_step", 2: "d2q9_step2 (two timesteps per launch)", 3: "d2q9_step3 (three timesteps per launch)",
-           4: "d2q9_step4 (four timesteps per launch)"}
+           4: "d2q9_step4 (four timesteps per launch)",
+           6: "d2q9_deep (up to 6 timesteps per launch, lanes of two cells)",
+           7: "d2q9_deep (up to 7 timesteps per launch, lanes of two cells)",
+           8: "d2q9_deep (up to 8 timesteps per launch, lanes of two cells)"}
 
 
 def cavity(nx, ny):
@@ -265,7 +268,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the nx x ny grid is split over the ranks; weak: every rank gets ny rows")
     ap.add_argument("--accel", type=float, default=0.005)
-    ap.add_argument("--fuse", type=int, default=-1, help="timesteps per launch of the register/LDS-window kernels: 0, 1 (= 2), 3, 4; -1: library default")
+    ap.add_argument("--fuse", type=int, default=-1, help="timesteps per launch of the register/LDS-window kernels: 0, 1 (= 2), 3, 4, 6..8 (d2q9_deep, at most); -1: library default")
     ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl"],
                     help="N > 1: halo transport(s) to measure; the faster one is `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -309,7 +312,7 @@ def main():
         sim, transports = lbm_amd.LBM(params, obstacles), [None]
     if args.fuse >= 0:
         sim.set_option("fuse", args.fuse)
-    fused = {0: 0, 1: 2, 3: 3, 4: 4}[sim.get_option("fuse")]   # timesteps per launch of the dominant kernel (0: one)
+    fused = {0: 0, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[sim.get_option("fuse")]   # timesteps per launch of the dominant kernel (0: one)
     multistep = sim.get_option("multistep")
     sim.upload(None)  # uniform rest state, built on the device
     y0, y1 = sim.row_range()
@@ -349,6 +352,10 @@ def main():
         # the dominant kernel advances `steps_per_launch` timesteps of the rank's slab per launch
         steps_per_launch = multistep if multistep else (fused if fused else 1)
         launches = args.steps // steps_per_launch + args.steps % steps_per_launch
+        if fused >= 6 and not multistep and args.steps >= 2:
+            # d2q9_deep: the run is split into the fewest launches, of equal depth (20 steps = 7+7+6)
+            launches = -(-args.steps // fused)
+            steps_per_launch = args.steps / launches
         launch_s = loop_ms * 1e-3 / launches
         cells_local = nx * rows_local
         model_bytes = (BYTES_PER_LU + MASK_BYTES) * cells_local
@@ -368,7 +375,7 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "kernel": ("d2q9_multi (%d timesteps per launch on LDS tiles)" % multistep) if multistep else KERNELS[fused],
-                "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": steps_per_launch,
+                "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": round(steps_per_launch, 3),
                 "model_bytes_per_launch": model_bytes,
                 "formula": "achieved = model_bytes_per_launch / launch_us; model_bytes_per_launch = (72 + 1) B x %d cells of the "
                            "rank's slab: a launch reads the grid once, writes it once and reads the byte mask, however many "
@@ -385,7 +392,7 @@ def main():
         if os.path.exists(tp) and world == 1 and not multistep:
             with open(tp) as f:
                 tj = json.load(f)
-            key = "%dx%d/step%d" % (nx, ny, steps_per_launch)
+            key = "%dx%d/%s" % (nx, ny, "deep" if fused >= 6 else "step%d" % steps_per_launch)
             if key in tj:
                 tb = tj[key]["hbm_bytes_per_launch"]
                 rf = out["roofline"]
@@ -470,7 +477,7 @@ def main():
                 ms2 = s2.run_timed(n2)
                 s2.sync()
                 w2 = time.perf_counter() - t1
-                f2 = {0: 1, 1: 2, 3: 3, 4: 4}[s2.get_option("fuse")]
+                f2 = {0: 1, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[s2.get_option("fuse")]
             out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat (both grids fit the 256 MiB Infinity Cache: "
                                        "these bytes come from cache, not HBM — profiles/r02_config3.txt)",
                            "value": round(1024 * 1024 * n2 / w2 / 1e6, 1), "unit": "MLUPS", "steps": n2, "us_per_step": round(ms2 / n2 * 1e3, 3),

@@ -1537,6 +1537,322 @@ __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *
   }
 }
 
+// ---- D timesteps per launch, two cells per lane ("deep" window kernel) --------------------------------------
+// The window kernels above hold four cells per lane: two LDS windows and one register window are all that fits two
+// waves per SIMD, so four steps per launch is their limit, and at four steps they move real traffic at 90-93 % of what
+// a copy reaches — only fewer bytes per update make the big grids faster.  This kernel halves the per-wave state
+// instead: a lane holds TWO neighbouring cells (one v2f per plane), a window slot is 512 B, D-1 windows fit
+// (D = 6: four in LDS, 18 KB per wave, one in registers), the grid is read once and written once per D steps.
+//  - the collision is written on explicit pairs (collide_pair: the operations of collide_cell, in its order, on both
+//    cells at once) and compiles to v_pk_* instructions without the pack/unpack moves the float4 kernels need;
+//  - planes that move along x are read back from the LDS window already shifted by one cell (an unaligned 8-byte read
+//    at +-4 bytes: ds_read2_b32) instead of DPP + moves; a wave runs ONE sweep direction as a template parameter, so
+//    the plane roles are fixed at compile time (no selects) — per cell and step 64 VALU instructions instead of 92;
+//  - what is known about a row (is it the accelerated row, is it one of the chunk's own rows) is computed once, for
+//    level 0, and travels to the deeper levels in scalar shift registers: level l works on the row level 0 had l
+//    iterations earlier.
+// Level l's output is valid from cell l inwards at either end of a strip, so a strip keeps 64 - 2*ceil((D-1)/2) output
+// lanes (58 for D = 6).  Same arithmetic per cell as everything else: bit-identical to D single steps.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float x) { v2f r = {x, x}; return r; }
+
+// collide_cell on the pair (cell a, cell b): every statement is collide_cell's, applied to both components; the sum
+// order of the density, the grouping of the momenta and every fused multiply-add are the same, so each component
+// rounds exactly as collide_cell does.  MAY_BE_OBSTACLE = false: the caller knows that no cell of the WAVE is blocked.
+template <bool MAY_BE_OBSTACLE = true>
+__device__ __forceinline__ v2f collide_pair(const v2f (&g)[9], bool oa_in, bool ob_in, float omega, v2f (&out)[9]) {
+#pragma clang fp contract(off)
+  const bool oa = MAY_BE_OBSTACLE && oa_in, ob = MAY_BE_OBSTACLE && ob_in;
+  const float w0 = 4.0f / 9.0f, w1 = 1.0f / 9.0f, w2 = 1.0f / 36.0f;
+  v2f dens = g[0] + g[1];
+  dens += g[2]; dens += g[3]; dens += g[4]; dens += g[5]; dens += g[6]; dens += g[7]; dens += g[8];
+  const v2f densinv = {__builtin_amdgcn_rcpf(dens.x), __builtin_amdgcn_rcpf(dens.y)};
+  const v2f da = g[5] - g[7], db = g[8] - g[6];
+  const v2f jx = (g[1] - g[3]) + (da + db);
+  const v2f jy = (g[2] - g[4]) + (da - db);
+  const v2f usq = fma2(jx, jx, jy * jy);
+  const v2f h = splat2(1.5f) * densinv;
+  const v2f c = fma2(-h, usq, dens);
+  const v2f h3 = splat2(3.0f) * h;
+  const v2f jp = jx + jy, jm = jx - jy;
+  const v2f ax = fma2(h3 * jx, jx, c), ay = fma2(h3 * jy, jy, c), ap = fma2(h3 * jp, jp, c), am = fma2(h3 * jm, jm, c);
+  v2f eq[9];
+  eq[0] = splat2(w0) * c;
+  eq[1] = splat2(w1) * fma2(splat2(3.0f), jx, ax); eq[3] = splat2(w1) * fma2(splat2(-3.0f), jx, ax);
+  eq[2] = splat2(w1) * fma2(splat2(3.0f), jy, ay); eq[4] = splat2(w1) * fma2(splat2(-3.0f), jy, ay);
+  eq[5] = splat2(w2) * fma2(splat2(3.0f), jp, ap); eq[7] = splat2(w2) * fma2(splat2(-3.0f), jp, ap);
+  eq[8] = splat2(w2) * fma2(splat2(3.0f), jm, am); eq[6] = splat2(w2) * fma2(splat2(-3.0f), jm, am);
+  constexpr int opp[9] = {0, 3, 4, 1, 2, 7, 8, 5, 6};  // kernels.cl:69
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const v2f r = fma2(splat2(omega), eq[k] - g[k], g[k]);
+    out[k].x = oa ? g[opp[k]].x : r.x;
+    out[k].y = ob ? g[opp[k]].y : r.y;
+  }
+  v2f u = {__builtin_amdgcn_sqrtf(usq.x) * densinv.x, __builtin_amdgcn_sqrtf(usq.y) * densinv.y};
+  u.x = oa ? 0.f : u.x;
+  u.y = ob ? 0.f : u.y;
+  return u;
+}
+
+// accelerate_cell on both cells of a pair (kernels.cl:24-42)
+__device__ __forceinline__ void accelerate_pair(v2f (&f)[9], bool oa, bool ob, float aw1, float aw2) {
+#pragma clang fp contract(off)
+  const bool ta = !oa && (f[3].x - aw1) > 0.0f && (f[6].x - aw2) > 0.0f && (f[7].x - aw2) > 0.0f;
+  const bool tb = !ob && (f[3].y - aw1) > 0.0f && (f[6].y - aw2) > 0.0f && (f[7].y - aw2) > 0.0f;
+  if (ta) { f[1].x += aw1; f[5].x += aw2; f[8].x += aw2; f[3].x -= aw1; f[6].x -= aw2; f[7].x -= aw2; }
+  if (tb) { f[1].y += aw1; f[5].y += aw2; f[8].y += aw2; f[3].y -= aw1; f[6].y -= aw2; f[7].y -= aw2; }
+}
+
+// one step on a pair: collision, then the next step's accelerate_flow if this is the accelerated row (the row is the
+// same for the whole wave: a scalar branch).  OBST = false: no cell of the wave is blocked.
+template <bool OBST>
+__device__ __forceinline__ float collide2(const v2f (&g)[9], uint32_t m, float omega, bool accel_uniform, float aw1, float aw2,
+                                          v2f (&o)[9]) {
+  const bool oa = (m & 0xffu) != 0, ob = (m & 0xff00u) != 0;
+  const v2f u = collide_pair<OBST>(g, oa, ob, omega, o);
+  if (accel_uniform) accelerate_pair(o, OBST && oa, OBST && ob, aw1, aw2);
+  return u.x + u.y;
+}
+
+// the pair shifted by one cell: lane i receives the odd cell of lane i-1 / the even cell of lane i+1
+__device__ __forceinline__ v2f pair_from_west(v2f p, float halo) { v2f r = {dpp_from_lane_below(p.y, halo), p.x}; return r; }
+__device__ __forceinline__ v2f pair_from_east(v2f p, float halo) { v2f r = {p.y, dpp_from_lane_above(p.x, halo)}; return r; }
+__device__ __forceinline__ v2f pair_from_west(v2f p) {
+  v2f r = {__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p.y), 0x138, 0xf, 0xf, true)), p.x};
+  return r;
+}
+__device__ __forceinline__ v2f pair_from_east(v2f p) {
+  v2f r = {p.y, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p.x), 0x130, 0xf, 0xf, true))};
+  return r;
+}
+
+struct PairLoads {
+  v2f c[9];
+  float h0, h1, h2;  // lane 0: west neighbours of planes 1,5,8; lane 63: east neighbours of planes 3,6,7
+  uint32_t m;        // the aligned 4 mask bytes that hold the two cells' (bytes 0,1 or 2,3: see deep_sweep's mask_shift)
+};
+template <bool NTL>
+__device__ __forceinline__ void issue_pair_loads(const Step2Args &a, int r, int xcol, int xhalo_w, int xhalo_e, int lane, PairLoads &in) {
+  const size_t ps = a.plane_stride, rs = a.row_stride;
+  const int r_s = (r == 0) ? a.ny - 1 : r - 1;
+  const int r_n = (r == a.ny - 1) ? 0 : r + 1;
+  const float *Rc = a.src + (size_t)r * rs, *Rs = a.src + (size_t)r_s * rs, *Rn = a.src + (size_t)r_n * rs;
+  auto ld = [&](const float *p) {
+    if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p + xcol));
+    return *reinterpret_cast<const v2f *>(p + xcol);
+  };
+  in.c[0] = ld(Rc); in.c[1] = ld(Rc + ps); in.c[3] = ld(Rc + 3 * ps);
+  in.c[2] = ld(Rs + 2 * ps); in.c[5] = ld(Rs + 5 * ps); in.c[6] = ld(Rs + 6 * ps);
+  in.c[4] = ld(Rn + 4 * ps); in.c[7] = ld(Rn + 7 * ps); in.c[8] = ld(Rn + 8 * ps);
+  // (a whole aligned dword, shifted after loads_ready(): a 16-bit load gets its zero-extension scheduled right behind
+  // the load, and the wait for the load with it)
+  in.m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)r * a.nx + (xcol & ~3));
+  in.h0 = in.h1 = in.h2 = 0.f;
+  if (lane == 0 || lane == 63) {
+    const bool lo = (lane == 0);
+    in.h0 = lo ? Rc[1 * ps + xhalo_w] : Rc[3 * ps + xhalo_e];
+    in.h1 = lo ? Rs[5 * ps + xhalo_w] : Rs[6 * ps + xhalo_e];
+    in.h2 = lo ? Rn[8 * ps + xhalo_w] : Rn[7 * ps + xhalo_e];
+  }
+}
+
+// A window of the deep kernel: slot s holds one v2f per lane at float (s*128 + 2*lane); slots 0..2 = planes 0,1,3 of
+// the middle row, slots 3+3p .. 5+3p = the three sweep-direction planes of the rows of parity p (written in iteration
+// k, read as the trail row in iteration k+2).  The register form keeps the two trail rows as S0 (older) and S1.
+constexpr int kPairSlotFloats = 128;
+constexpr int kPairWinFloats = 9 * kPairSlotFloats;
+struct PairWindow { v2f mid[3], S0[3], S1[3]; };
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };
+__device__ __forceinline__ v2f lds_pair(const float *p) { return *reinterpret_cast<const v2f *>(p); }
+__device__ __forceinline__ v2f lds_pair_shifted(const float *p) {  // 4-byte aligned: one ds_read2_b32
+  const f2u t = *reinterpret_cast<const f2u *>(p);
+  v2f r = {t.x, t.y};
+  return r;
+}
+__device__ __forceinline__ void lds_pair_put(float *p, v2f v) { *reinterpret_cast<v2f *>(p) = v; }
+
+constexpr int deep_halo_lanes(int D) { return D / 2; }           // ceil((D-1)/2) lanes of two cells at either end of a strip
+constexpr int deep_lds_windows(int D) { return D - 1 < 4 ? D - 1 : 4; }  // 4 x 4.5 KB + 1 register window: two waves per SIMD
+
+template <int D, int WL, bool UP, bool NT, bool OBST_PATHS>
+__device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, float *lds, float *partials, int pstride, int ys, int ye,
+                                           int xcol, int xhalo_w, int xhalo_e, int lane, bool owner, int unit) {
+  // L = timesteps this launch advances (2 .. D, wave-uniform): the run's last launches are shallower.  All row
+  // arithmetic is in terms of L; D bounds the unrolled level loop and fixes the halo lanes.
+  const size_t ps = a.plane_stride;
+  auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
+  const int n = ye - ys, d = UP ? 1 : -1;
+  const int r0 = UP ? ys - (L - 1) : ye + (L - 2);  // level 0 works on row r0 + k*d in iteration k = 0 .. n+2(L-1)-1,
+  const int last = n + 2 * (L - 1) - 1;             // level l on row r0 + (k-l)*d from iteration 2l on
+  float sum[D];
+  constexpr int NR = (D - 1 - WL) > 0 ? (D - 1 - WL) : 1;
+  PairWindow w[NR];
+  uint32_t m_mid[D - 1];
+#pragma unroll
+  for (int l = 0; l < D; l++) sum[l] = 0.f;
+#pragma unroll
+  for (int l = 0; l < D - 1; l++) m_mid[l] = 0;
+#pragma unroll
+  for (int l = 0; l < NR; l++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) w[l].mid[i] = w[l].S0[i] = w[l].S1[i] = splat2(0.f);
+  }
+  float *const lw = lds + 2 + 2 * lane;  // + 2 floats: lane 0 reads one float below its slot
+  uint32_t accbits = 0, ownbits = 0;     // bit l: the row level l works on is the accelerated row / one of the chunk's own
+  const uint32_t accmask = a.accel_next ? 0xffffffffu : ~(1u << (L - 1));  // the last level's output is the stored state
+  const uint32_t mask_shift = (xcol & 2) * 8;  // nx % 4 == 0: the pair's two mask bytes are the low or the high half of a dword
+  PairLoads in;
+  issue_pair_loads<false>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, in);
+  // the six window planes level l (1 .. D-1) gathers from: middle row (0, 1 from the west, 3 from the east) and trail row
+  auto window_read = [&](int l, int par, v2f (&q)[6]) __attribute__((always_inline)) {
+    if ((l - 1) < WL) {
+      const float *W = lw + (l - 1) * kPairWinFloats;
+      const float *Wp = W + (3 + 3 * par) * kPairSlotFloats;
+      q[0] = lds_pair(W); q[1] = lds_pair_shifted(W + kPairSlotFloats - 1); q[2] = lds_pair_shifted(W + 2 * kPairSlotFloats + 1);
+      q[3] = lds_pair(Wp); q[4] = lds_pair_shifted(Wp + kPairSlotFloats - 1); q[5] = lds_pair_shifted(Wp + 2 * kPairSlotFloats + 1);
+    } else {
+      const PairWindow &R = w[(l - 1) < WL ? 0 : (l - 1 - WL)];
+      q[0] = R.mid[0]; q[1] = pair_from_west(R.mid[1]); q[2] = pair_from_east(R.mid[2]);
+      q[3] = R.S0[0]; q[4] = pair_from_west(R.S0[1]); q[5] = pair_from_east(R.S0[2]);
+    }
+  };
+  v2f out[9];  // the last level's row of the previous iteration
+#pragma unroll
+  for (int kk = 0; kk < 9; kk++) out[kk] = splat2(0.f);
+  auto store_row = [&](int kprev) __attribute__((always_inline)) {
+    if (owner) {
+      float *dp = a.dst + (size_t)(r0 + (kprev - (L - 1)) * d) * a.row_stride + xcol;
+#pragma unroll
+      for (int kk = 0; kk < 9; kk++) {
+        if (NT) __builtin_nontemporal_store(out[kk], reinterpret_cast<v2f *>(dp + kk * ps));
+        else *reinterpret_cast<v2f *>(dp + kk * ps) = out[kk];
+      }
+    }
+  };
+  for (int k = 0; k <= last; k++) {
+    const int par = k & 1;
+    v2f top[9], pre[2][6];  // pre[l & 1]: the window planes of level l, read one level ahead
+    uint32_t m_top;
+    const int row0 = wrap(r0 + k * d);
+    accbits = ((accbits << 1) | ((row0 == a.accel_row || row0 == a.accel_row_b) ? 1u : 0u)) & accmask;
+    ownbits = (ownbits << 1) | ((k >= L - 1 && k <= n + L - 2) ? 1u : 0u);
+    if (k >= 2) window_read(1, par, pre[1]);  // issued before level 0's arithmetic: the LDS latency hides behind it
+    {  // level 0: step t+1 of row0 from the loaded source rows
+      v2f g[9];
+      g[0] = in.c[0]; g[2] = in.c[2]; g[4] = in.c[4];
+      g[1] = pair_from_west(in.c[1], in.h0); g[5] = pair_from_west(in.c[5], in.h1); g[8] = pair_from_west(in.c[8], in.h2);
+      g[3] = pair_from_east(in.c[3], in.h0); g[6] = pair_from_east(in.c[6], in.h1); g[7] = pair_from_east(in.c[7], in.h2);
+      m_top = in.m >> mask_shift;  // (bits 16.. may hold the neighbouring pair's bytes: every test masks)
+      float t;
+      if (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_top & 0xffffu) != 0) == 0ull) t = collide2<false>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
+      else t = collide2<true>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
+      if ((ownbits & 1u) && owner) sum[0] += t;
+      // The row the last level finished in the PREVIOUS iteration is stored here, right before this iteration's loads:
+      // the wave waits for its loads at the top of the next iteration with the memory counter at zero, stores
+      // included — with the stores at the end of an iteration that wait exposed the round trip of stores just issued;
+      // now everything it covers was issued a whole iteration of arithmetic earlier.
+      if (k - 1 >= 2 * (L - 1)) store_row(k - 1);
+      // (unconditional: the last iteration loads its own row once more rather than branching around the loads)
+      issue_pair_loads<false>(a, wrap(r0 + (k < last ? k + 1 : k) * d), xcol, xhalo_w, xhalo_e, lane, in);
+    }
+#pragma unroll
+    for (int l = 1; l < D; l++) {
+      const bool final = (l == D - 1) || (l == L - 1);  // (level l exists: the level before it was not the last)
+      v2f nxt[9];
+      uint32_t m_nxt = 0;
+      const bool active = k >= 2 * l;
+      const bool in_lds = (l - 1) < WL;
+      float *const W = lw + (l - 1) * kPairWinFloats;
+      float *const Wp = W + (3 + 3 * par) * kPairSlotFloats;
+      PairWindow &R = w[in_lds ? 0 : (l - 1 - WL)];
+      if (active) {
+        const v2f (&q)[6] = pre[l & 1];
+        if (l + 1 < D && !final && k >= 2 * (l + 1)) window_read(l + 1, par, pre[(l + 1) & 1]);  // the next level's window, early
+        v2f g[9];
+        g[0] = q[0]; g[1] = q[1]; g[3] = q[2];
+        if (UP) {  // the trail row is the row below: its planes 2,5,6 arrive; the newest row is above: 4,7,8
+          g[2] = q[3]; g[5] = q[4]; g[6] = q[5];
+          g[4] = top[4]; g[8] = pair_from_west(top[8]); g[7] = pair_from_east(top[7]);
+        } else {
+          g[4] = q[3]; g[8] = q[4]; g[7] = q[5];
+          g[2] = top[2]; g[5] = pair_from_west(top[5]); g[6] = pair_from_east(top[6]);
+        }
+        m_nxt = m_mid[l - 1];
+        const bool acc = ((accbits >> l) & 1u) != 0;
+        float t;
+        if (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_nxt & 0xffffu) != 0) == 0ull) t = collide2<false>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
+        else t = collide2<true>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
+        if (!final) {
+          if (((ownbits >> l) & 1u) && owner) sum[l] += t;
+        } else {  // the last level: every row it works on is one of the chunk's own; stored in the NEXT iteration
+          if (owner) sum[l] += t;
+#pragma unroll
+          for (int kk = 0; kk < 9; kk++) out[kk] = nxt[kk];
+        }
+      }
+      // `top` becomes the window's middle row, its sweep-direction planes the newest trail row
+      if (in_lds) {
+        lds_pair_put(W, top[0]); lds_pair_put(W + kPairSlotFloats, top[1]); lds_pair_put(W + 2 * kPairSlotFloats, top[3]);
+        lds_pair_put(Wp, UP ? top[2] : top[4]);
+        lds_pair_put(Wp + kPairSlotFloats, UP ? top[5] : top[8]);
+        lds_pair_put(Wp + 2 * kPairSlotFloats, UP ? top[6] : top[7]);
+      } else {
+        R.mid[0] = top[0]; R.mid[1] = top[1]; R.mid[2] = top[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) R.S0[i] = R.S1[i];
+        R.S1[0] = UP ? top[2] : top[4]; R.S1[1] = UP ? top[5] : top[8]; R.S1[2] = UP ? top[6] : top[7];
+      }
+      m_mid[l - 1] = m_top;
+      if (!active || final) break;
+      if (l < D - 1) {
+#pragma unroll
+        for (int kk = 0; kk < 9; kk++) top[kk] = nxt[kk];
+        m_top = m_nxt;
+      }
+    }
+  }
+  store_row(last);
+#pragma unroll
+  for (int l = 0; l < D; l++) {
+    if (l >= L) break;
+    const float s = wave_sum(sum[l]);
+    if (lane == 0) partials[(size_t)l * pstride + unit] = s;
+  }
+}
+
+// nlev = timesteps the launch advances (2 .. D); partials: [nlev][pstride], slot l*pstride + unit = the unit's sum of
+// |j|/rho after step t+1+l
+template <int D, bool NT, bool OBST_PATHS = false>
+__global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *partials, int pstride, int nlev) {
+  constexpr int WL = deep_lds_windows(D), HL = deep_halo_lanes(D);
+  __shared__ float lds[WL * kPairWinFloats + 4];
+  const int lane = threadIdx.x;
+  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
+  if (slot >= a.units_per_band) return;
+  const int unit = band * a.units_per_band + slot;
+  const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
+  const int ys = a.chunk_start[chunk], ye = a.chunk_start[chunk + 1];
+  if (ys >= ye || chunk == a.skip_chunk) {
+    if (lane < nlev) partials[(size_t)lane * pstride + unit] = 0.f;
+    return;
+  }
+  const int q2 = a.nx >> 1;
+  const int qcol = strip * a.lanes_out + lane - HL;
+  const bool owner = (lane >= HL) && (lane < HL + a.lanes_out) && (qcol < q2);
+  int qw = qcol % q2;
+  if (qw < 0) qw += q2;
+  const int xcol = qw * 2;
+  const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
+  const int xhalo_e = (xcol + 2 >= a.nx) ? 0 : xcol + 2;
+  // even chunks sweep up, odd chunks down: neighbouring chunks meet at their common boundary rows at about the same time
+  if (__builtin_amdgcn_readfirstlane((int)((chunk & 1) == 0)))
+    deep_sweep<D, WL, true, NT, OBST_PATHS>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+  else
+    deep_sweep<D, WL, false, NT, OBST_PATHS>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+}
+
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------
 // Grids of a few hundred cells a side are bound by launch latency, not bandwidth (one step of 128x128 is
 // ~2 us of work behind ~3.4 us of launch cost).  This kernel advances T <= kMultiMaxT steps per launch: a

@@ -104,6 +104,8 @@ int load_rccl() {
   } while (0)
 
 constexpr bool kStep3LdsDefault = true;   // d2q9_step3 windows in LDS unless option "windows" says otherwise
+constexpr int kDeepSteps = 8;    // most timesteps per launch of d2q9_deep (option fuse = 6..8: the limit of a context)
+constexpr int kDeepMin = 6;
 constexpr int kRingMax = 256;  // most steps of per-workgroup partial sums buffered between reductions
 constexpr int kProfSets = 64, kProfEvents = 5;  // lbm_run_profiled: {edge start, edge end, exchange end, interior start, interior end}
 enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2, TRANSPORT_PEER = 3 };
@@ -167,6 +169,8 @@ struct Slab {
   FuseGeom f_main, f_edge;        // whole slab (one slab) or interior chunks; the two edge chunks
   FuseGeom f3_main;               // schedule of d2q9_step3: its own chunk lengths
   FuseGeom f4_main;               // schedule of d2q9_step4 (one slab only): long chunks
+  FuseGeom f6_main;               // schedule of d2q9_deep (one slab, no halo rows): its own strips of two-cell lanes
+  int strips2 = 0, lanes2 = 0;    // x decomposition of d2q9_deep: strips per row, output lanes (of two cells) per strip
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
   int m_tx = 32, m_ty = 16;          // its tile size (chosen by how many tiles the slab gives)
@@ -227,6 +231,7 @@ struct lbm_ctx {
   int load_bufs = 0;        // d2q9_step3 row-sets of loads in flight: 1, 2, 0 = auto
   int sched_waves = 0;      // waves per SIMD the d2q9_step3 schedule plans for: 1, 2, 0 = auto
   int pair = -1;            // d2q9_step3p (chunk pairs share their start-up rows): 1 on, 0 off, -1 auto
+  int obst_paths = -1;      // d2q9_deep: 1 (and -1, auto) = a second collision path without bounce-back selects for waves without blocked cells
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
   int chunk_min = 0;        // shortest chunk at the tapered end of a band (0 = auto)
@@ -290,6 +295,8 @@ bool fuse_possible(const lbm_ctx *c) {
   if (!c->vec4 || c->p.nx < 256) return false;
   return c->rows_min >= 8;
 }
+// d2q9_deep: one slab holding the whole periodic grid (no halo rows yet), rows for its 2*(kDeepSteps-1) start-up iterations
+bool deep_possible(const lbm_ctx *c) { return fuse_possible(c) && !c->halo_mode && c->rows_min >= 4 * kDeepSteps; }
 // 0 = one launch per step, 2 = d2q9_step2, 3 = d2q9_step3 (falls back to 2 for the last steps of a run and
 // where the halo rows are fewer than 3)
 int fuse_level(const lbm_ctx *c) {
@@ -306,7 +313,14 @@ int fuse_level(const lbm_ctx *c) {
     // 2048x2048 183 / 223, 4096x4096 217 / 273, 8192x8192 230 / 295)
     const long cells = (long)c->p.nx * c->rows_min;
     lvl = cells >= 1280L * 1024 ? 4 : (cells > 450L * 1024 ? 3 : 2);
+    // ... and six (d2q9_deep) from 8M cells up on one slab without halo rows (tools/ab.py, four / six steps: 4096x4096
+    // 272 / 272, 8192x1024 244 / 254, 8192x2048 278 / 285, 8192x4096 292 / 317, 6144x6144 276 / 327, 8192x8192 301 / 354,
+    // 16384x8192 299 / 362 GLUPS; below: 2048x2048 222 / 227, 1024x1024 137 / 125)
+    // (one launch by the steps it advances, 8192x8192, tools/depth_sweep.py: 2..4 steps 940-965 us — the pass over the grid,
+    // as long as the four-step kernel's launch —, 5: 1007, 6: 1113, 7: 1304, 8: 1455 us = 369 GLUPS)
+    if (cells >= 8L << 20 && deep_possible(c)) lvl = kDeepSteps;
   }
+  if (lvl > 4 && !(lvl >= kDeepMin && lvl <= kDeepSteps && deep_possible(c))) lvl = 4;
   if (lvl == 4 && ((c->halo_mode && c->halo_depth < 4) || !windows_in_lds(c))) lvl = 3;  // needs 4 halo rows, LDS windows
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
   return lvl;
@@ -346,8 +360,9 @@ bool compact_sets(const lbm_ctx *c) {
 // `cmax` rows and ends with ever shorter ones (guided self-scheduling), down to `cmin`.  (R full rounds of equal
 // chunks instead of the taper: within +-2 % on 8192x1024 ... 8192x8192, no consistent sign — not adopted.)
 int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g, int waves_per_simd = 2,
-                  int reserve = 0, bool pairs = false) {
+                  int reserve = 0, bool pairs = false, int strips_of_kernel = 0) {
   const int rows = r1 - r0;
+  const int strips = strips_of_kernel > 0 ? strips_of_kernel : s.strips;
   g.nbands = (allow_bands && rows >= 8 * 4 * cmin) ? 8 : 1;
   // CUs x SIMDs x waves per SIMD the kernel's registers / LDS allow, minus the wave slots a concurrent launch needs
   // (slab mode: the edge launch, which must find its slots at once — see slab_geometry)
@@ -361,7 +376,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     int best_nb = 8;
     double best = -1.0;
     for (int nb = 8; nb >= 1; nb /= 2) {
-      const int fl = std::max(2, (int)std::floor((double)waves_resident / nb / s.strips) & ~1);
+      const int fl = std::max(2, (int)std::floor((double)waves_resident / nb / strips) & ~1);
       const int nrows = div_up(rows, nb);
       if ((int)std::ceil((double)nrows / fl) > cmax) continue;  // not a one-round schedule with this band count
       const double busy = (double)std::min(fl, nrows) * nb * (1.0 + 0.01 * nb);
@@ -369,7 +384,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     }
     g.nbands = best_nb;
   }
-  double slots = std::max(1.0, (double)waves_resident / g.nbands / s.strips);  // concurrent chunks per band
+  double slots = std::max(1.0, (double)waves_resident / g.nbands / strips);  // concurrent chunks per band
   if (pairs) slots = std::max(2.0, (double)((int)std::floor(slots) & ~1));
   std::vector<int> starts;
   int chunks_per_band = 0;
@@ -386,7 +401,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     // (one round only if the units really are resident at once: a pair schedule needs two slots per band and strip —
     // with fewer, "one round" of 64-row chunks was 2192 units on 1500 free slots and the last workgroups started when the
     // first had finished: compact 8192x1024 slab 212 instead of 220 GLUPS)
-    const bool fits = (double)waves_resident / g.nbands / s.strips >= (pairs ? 2.0 : 1.0);
+    const bool fits = (double)waves_resident / g.nbands / strips >= (pairs ? 2.0 : 1.0);
     const bool single_round = one_round <= cmax && fits;
     if (b == 0) g.single_round = single_round;
     while (rem > 0) {
@@ -409,7 +424,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
   }
   starts.push_back(r1);
   g.nchunks = chunks_per_band * g.nbands;
-  g.units_per_band = chunks_per_band * s.strips;
+  g.units_per_band = chunks_per_band * strips;
   g.units = g.units_per_band * g.nbands;
   if (set_dev(s)) return LBM_ERR_HIP;
   if (g.chunk_start) HIP_TRY(hipFree(g.chunk_start));
@@ -562,6 +577,19 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       s.nb_total = std::max(s.nb_total, s.f3_main.units);
       if (int rc = fuse_schedule_pairs(c, s, 0, s.rows, c4max, c4min, s.f4_main, step4_sched_waves(c), 0, windows_in_lds(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f4_main.units);
+      if (deep_possible(c)) {
+        // d2q9_deep: lanes of two cells, deep_halo_lanes() of them idle at either end of a strip; strips start on 64-byte
+        // boundaries (8 lanes).  2*(D-1) redundant start-up iterations per chunk -> long chunks.
+        const int q2 = c->p.nx / 2, lmax = 64 - 2 * lbm::deep_halo_lanes(kDeepSteps);
+        s.strips2 = div_up(q2, lmax / 8 * 8);
+        s.lanes2 = std::min(lmax, (div_up(q2, s.strips2) + 7) / 8 * 8);
+        const int c6max = std::max(8, std::min(c->chunk_rows > 0 ? c->chunk_rows : 96, s.rows));
+        const int c6min = std::max(4, std::min(c->chunk_min > 0 ? c->chunk_min : 24, c6max));
+        if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_main, 2, 0, false, s.strips2)) return rc;
+        s.nb_total = std::max(s.nb_total, s.f6_main.units);
+      } else {
+        s.f6_main.units = 0;
+      }
     }
   }
   return LBM_OK;
@@ -702,6 +730,18 @@ void launch_step4(const lbm_ctx *c, const Step2Args &a0, float *partials3, float
 }
 
 // compact launch set of the three- / four-step kernels: edge units first, then the interior units, one launch
+void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, float *partials, int nlev, hipStream_t st) {
+  Step2Args a = a0;
+  a.strips = s.strips2;
+  a.lanes_out = s.lanes2;
+  const dim3 grid(s.f6_main.units), block(64);
+  const bool nt = nt_effective(c), paths = c->obst_paths != 0;  // (-1 auto = on)
+  if (nt && paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+}
+
 void launch_compact(int level, bool paired, const Step2Args &a0, float *partials3, float *partials4, int main_units, hipStream_t st) {
   Step2Args a = a0;
   if (paired) {
@@ -912,7 +952,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
     }
 
   int batch_first = c->steps_done;
-  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4, KIND_FUSED4 = 5 };
+  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4, KIND_FUSED4 = 5, KIND_DEEP = 6 };
   int batch_kind = KIND_NONE;  // launch kind of the steps buffered in the ring (their slot occupancy differs)
   int last_q = 1;
   const int multi_T = multistep_effective(c);
@@ -927,6 +967,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (batch_kind == KIND_FUSED2) used = s.f_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED3) used = s.f3_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED4) used = s.f4_main.units + (multi ? s.f_edge.units : 0);
+      if (batch_kind == KIND_DEEP) used = s.f6_main.units;
       if (batch_kind == KIND_MULTI) used = s.m_tiles_x * s.m_tiles_y;
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
@@ -956,6 +997,11 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
     if (multi_T > 0) {
       kind = KIND_MULTI;
       adv = std::min(multi_T, nsteps - i);
+    } else if (fuse_lvl >= kDeepMin && nsteps - i >= 2) {
+      // the remaining steps in as few launches as possible, of equal depth (every launch moves the whole grid once:
+      // 20 steps = 7+7+6, not 8+8+4)
+      kind = KIND_DEEP;
+      adv = div_up(nsteps - i, div_up(nsteps - i, fuse_lvl));
     } else if (fuse_lvl == 4 && nsteps - i >= 4) {
       kind = KIND_FUSED4;
       adv = 4;
@@ -982,6 +1028,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           a.partials = slot1;
           a.ty_begin = 0; a.ty_split = s.m_tiles_y; a.ty_begin2 = 0;
           launch_multi(s, a, s.m_tiles_y, s.s_main);
+        } else if (kind == KIND_DEEP) {
+          launch_deep(c, s, base_args2(c, s, src, !last, s.f6_main), slot1, adv, s.s_main);
         } else if (kind == KIND_FUSED4) {
           Step2Args a = base_args2(c, s, src, !last, s.f4_main);
           a.partials1 = slot1;
@@ -1258,6 +1306,7 @@ void free_slab(Slab &s) {
   if (s.f_edge.chunk_start) hipFree(s.f_edge.chunk_start);
   if (s.f3_main.chunk_start) hipFree(s.f3_main.chunk_start);
   if (s.f4_main.chunk_start) hipFree(s.f4_main.chunk_start);
+  if (s.f6_main.chunk_start) hipFree(s.f6_main.chunk_start);
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
@@ -1934,9 +1983,14 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     return c->halo_mode ? rebuild_geometry(c) : LBM_OK;   // (whether launch sets are compact depends on it)
   }
   if (!strcmp(key, "fuse")) {
-    if (value < -1 || value > 4) return fail(LBM_ERR_ARG, "fuse must be -1 (auto), 0, 1 (or 2), 3 or 4");
+    if (value < -1 || value > kDeepSteps || value == 5) return fail(LBM_ERR_ARG, "fuse must be -1 (auto), 0, 1 (or 2), 3, 4 or 6..8");
     c->fuse = (int)value;
     return c->halo_mode ? rebuild_geometry(c) : LBM_OK;
+  }
+  if (!strcmp(key, "obst_paths")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "obst_paths must be -1 (auto), 0 or 1");
+    c->obst_paths = (int)value;
+    return LBM_OK;
   }
   if (!strcmp(key, "tile_shape")) {
     if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "tile_shape must be -1..2");
@@ -2024,7 +2078,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
   else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
-  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
+  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "halo_sync")) *value = c->halo_sync;
   else if (!strcmp(key, "compact")) *value = compact_sets(c);
