@@ -99,7 +99,7 @@ int lbm_connect_peers(lbm_ctx *ctx, const void *south_info, const void *north_in
  * Process-wide defaults for contexts created afterwards (validated; replace the environment hooks of round 1):
  *   "force_halo"  0 | 1   a single slab also carries halo rows and exchanges them with itself (a ring of one): the
  *                         whole multi-GPU machinery of a rank on one GPU (tests, tools/scaling_projection.py)
- *   "halo_depth"  0 = by slab size (8 small slabs / 4 from 2M cells / 3 / 2 thin slabs), else 2..8
+ *   "halo_depth"  0 = by slab size (8 small slabs and slabs from 5M cells / 4 from 2M cells / 3 / 2 thin slabs), else 2..8
  *   "transport"   0 = auto, 1 = RCCL send/recv, 2 = device-to-device copies, 3 = peer stores
  *   "lanes_out"   0 = auto (60), else 4..62: output lanes per 64-lane strip of the window kernels
  */
@@ -174,7 +174,13 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "fuse"         1 (or 2) = advance two timesteps per launch (intermediate state kept in registers, half
  *                  the HBM traffic), 3 = three timesteps per launch (two windows of intermediate rows, a third
  *                  of the traffic), 4 = four timesteps per launch (with row slabs only where the halo rows are 4
- *                  deep — slabs of 2M cells and more — else 3), 0 = one launch per step, -1 = auto (by size).
+ *                  deep — slabs of 2M cells and more — else 3), 6..8 = the deep window kernel (lanes of two cells) with
+ *                  at most that many timesteps per launch: a run is cut into the fewest launches, of equal depth
+ *                  (20 steps = 7 + 7 + 6); with row slabs capped by the halo depth (8 for slabs of 5M cells and more);
+ *                  falls back to 4 on grids under 32 rows per slab.  0 = one launch per step, -1 = auto (by size: 8
+ *                  from 5M cells per slab).
+ *   "obst_paths"   deep window kernel: 1 (and -1, auto) = waves that hold no blocked cell take a collision path without
+ *                  the bounce-back selects, 0 = one path
  *   "windows"      where the three-step kernel keeps its two windows: 1 = LDS (two waves per SIMD), 0 = registers
  *                  (one wave per SIMD), -1 = auto (1)
  *   "load_bufs"    row-sets of source loads the three-step kernel keeps in flight: 1 or 2, 0 = auto

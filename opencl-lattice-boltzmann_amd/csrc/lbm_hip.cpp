@@ -169,7 +169,8 @@ struct Slab {
   FuseGeom f_main, f_edge;        // whole slab (one slab) or interior chunks; the two edge chunks
   FuseGeom f3_main;               // schedule of d2q9_step3: its own chunk lengths
   FuseGeom f4_main;               // schedule of d2q9_step4 (one slab only): long chunks
-  FuseGeom f6_main;               // schedule of d2q9_deep (one slab, no halo rows): its own strips of two-cell lanes
+  FuseGeom f6_main;               // schedule of d2q9_deep: its own strips of two-cell lanes (whole slab, or the interior)
+  FuseGeom f6_edge;               // slab mode: its edge schedule {bottom edge rows, (interior), top edge rows}
   int strips2 = 0, lanes2 = 0;    // x decomposition of d2q9_deep: strips per row, output lanes (of two cells) per strip
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
@@ -295,8 +296,11 @@ bool fuse_possible(const lbm_ctx *c) {
   if (!c->vec4 || c->p.nx < 256) return false;
   return c->rows_min >= 8;
 }
-// d2q9_deep: one slab holding the whole periodic grid (no halo rows yet), rows for its 2*(kDeepSteps-1) start-up iterations
-bool deep_possible(const lbm_ctx *c) { return fuse_possible(c) && !c->halo_mode && c->rows_min >= 4 * kDeepSteps; }
+// d2q9_deep: rows for its 2*(kDeepSteps-1) start-up iterations; with halo rows, at least kDeepMin of them (a launch set
+// advances at most as many steps as the halos are deep)
+bool deep_possible(const lbm_ctx *c) {
+  return fuse_possible(c) && c->rows_min >= 4 * kDeepSteps && (!c->halo_mode || c->halo_depth >= kDeepMin);
+}
 // 0 = one launch per step, 2 = d2q9_step2, 3 = d2q9_step3 (falls back to 2 for the last steps of a run and
 // where the halo rows are fewer than 3)
 int fuse_level(const lbm_ctx *c) {
@@ -318,9 +322,12 @@ int fuse_level(const lbm_ctx *c) {
     // 16384x8192 299 / 362 GLUPS; below: 2048x2048 222 / 227, 1024x1024 137 / 125)
     // (one launch by the steps it advances, 8192x8192, tools/depth_sweep.py: 2..4 steps 940-965 us — the pass over the grid,
     // as long as the four-step kernel's launch —, 5: 1007, 6: 1113, 7: 1304, 8: 1455 us = 369 GLUPS)
-    if (cells >= 8L << 20 && deep_possible(c)) lvl = kDeepSteps;
+    // (with the band count of a one-round schedule chosen freely, r02: 2048x2048 220 / 222, 3072x2048 232 / 252, 4096x2048
+    // 251 / 268, 3072x3072 242 / 272, 4096x4096 270 / 323, 8192x1024 256 / 277, 8192x2048 275 / 317, 8192x8192 293 / 367)
+    if (cells >= 5L << 20 && deep_possible(c)) lvl = kDeepSteps;
   }
   if (lvl > 4 && !(lvl >= kDeepMin && lvl <= kDeepSteps && deep_possible(c))) lvl = 4;
+  if (lvl >= kDeepMin && c->halo_mode) lvl = std::min(lvl, c->halo_depth);
   if (lvl == 4 && ((c->halo_mode && c->halo_depth < 4) || !windows_in_lds(c))) lvl = 3;  // needs 4 halo rows, LDS windows
   if (lvl == 3 && c->halo_mode && c->halo_depth < 3) lvl = 2;
   return lvl;
@@ -372,11 +379,15 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
   // per band means 6 chunks with 8 bands (82 % of the slots) but 14 with 4 bands (96 %) — take the band count that
   // keeps most waves busy, preferring more bands (neighbouring strips then share an XCD's L2).
   g.single_round = false;
-  if (pairs && g.nbands == 8) {
+  // (the same choice for d2q9_deep, unpaired: 4096x4096 has 6.9 slots per band and strip with 8 bands — 6 chunks, 87 % of
+  // the slots, 85 rows + 14 start-up iterations each — but 55 per strip with one band: 75 rows + 14)
+  const bool flex_bands = strips_of_kernel > 0;
+  if ((pairs || flex_bands) && g.nbands == 8) {
     int best_nb = 8;
     double best = -1.0;
     for (int nb = 8; nb >= 1; nb /= 2) {
-      const int fl = std::max(2, (int)std::floor((double)waves_resident / nb / strips) & ~1);
+      const int fl = pairs ? std::max(2, (int)std::floor((double)waves_resident / nb / strips) & ~1)
+                           : std::max(1, (int)std::floor((double)waves_resident / nb / strips));
       const int nrows = div_up(rows, nb);
       if ((int)std::ceil((double)nrows / fl) > cmax) continue;  // not a one-round schedule with this band count
       const double busy = (double)std::min(fl, nrows) * nb * (1.0 + 0.01 * nb);
@@ -451,6 +462,42 @@ int fuse_schedule_pairs(const lbm_ctx *c, const Slab &s, int r0, int r1, int cma
     }
   }
   return fuse_schedule(s, r0, r1, cmax, cmin, true, g, waves_per_simd, reserve, false);
+}
+
+// Schedules of d2q9_deep for a slab: lanes of two cells, deep_halo_lanes() of them idle at either end of a strip; strips
+// start on 64-byte boundaries (8 lanes).  2*(D-1) redundant start-up iterations per chunk -> long chunks.
+int deep_geometry(const lbm_ctx *c, Slab &s) {
+  s.f6_main.units = s.f6_edge.units = 0;
+  if (!deep_possible(c)) return LBM_OK;
+  const int q2 = c->p.nx / 2, lmax = 64 - 2 * lbm::deep_halo_lanes(kDeepSteps);
+  s.strips2 = div_up(q2, lmax / 8 * 8);
+  s.lanes2 = std::min(lmax, (div_up(q2, s.strips2) + 7) / 8 * 8);
+  const int c6max = std::max(8, std::min(c->chunk_rows > 0 ? c->chunk_rows : 96, s.rows));
+  const int c6min = std::max(4, std::min(c->chunk_min > 0 ? c->chunk_min : 24, c6max));
+  if (!c->halo_mode) {
+    if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_main, 2, 0, false, s.strips2)) return rc;
+    s.nb_total = std::max(s.nb_total, s.f6_main.units);
+    return LBM_OK;
+  }
+  // slab mode: the edge launch computes the edge_rows rows at either end of the slab (one chunk each), the interior
+  // launch the rest and leaves the edge launch its wave slots (see slab_geometry)
+  FuseGeom &e = s.f6_edge;
+  const int tab[4] = {s.row0, s.row0 + s.edge_rows, s.row0 + s.rows - s.edge_rows, s.row0 + s.rows};
+  if (set_dev(s)) return LBM_ERR_HIP;
+  if (e.chunk_start) HIP_TRY(hipFree(e.chunk_start));
+  e.chunk_start = nullptr;
+  if (dev_alloc(&e.chunk_start, 4)) return LBM_ERR_HIP;
+  HIP_TRY(hipMemcpy(e.chunk_start, tab, sizeof(tab), hipMemcpyHostToDevice));
+  e.nchunks = 3;
+  e.skip = 1;
+  e.nbands = 1;
+  e.units_per_band = e.nchunks * s.strips2;
+  e.units = e.units_per_band;
+  const int i0 = tab[1], i1 = tab[2];
+  if (i1 > i0)
+    if (int rc = fuse_schedule(s, i0, i1, c6max, c6min, true, s.f6_main, 2, 2 * 2 * s.strips2, false, s.strips2)) return rc;
+  s.nb_total = std::max(s.nb_total, s.f6_main.units + e.units);
+  return LBM_OK;
 }
 
 // All launch geometry of a slab (single-step workgroup counts, fused schedules, ring slot stride).
@@ -577,20 +624,8 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       s.nb_total = std::max(s.nb_total, s.f3_main.units);
       if (int rc = fuse_schedule_pairs(c, s, 0, s.rows, c4max, c4min, s.f4_main, step4_sched_waves(c), 0, windows_in_lds(c))) return rc;
       s.nb_total = std::max(s.nb_total, s.f4_main.units);
-      if (deep_possible(c)) {
-        // d2q9_deep: lanes of two cells, deep_halo_lanes() of them idle at either end of a strip; strips start on 64-byte
-        // boundaries (8 lanes).  2*(D-1) redundant start-up iterations per chunk -> long chunks.
-        const int q2 = c->p.nx / 2, lmax = 64 - 2 * lbm::deep_halo_lanes(kDeepSteps);
-        s.strips2 = div_up(q2, lmax / 8 * 8);
-        s.lanes2 = std::min(lmax, (div_up(q2, s.strips2) + 7) / 8 * 8);
-        const int c6max = std::max(8, std::min(c->chunk_rows > 0 ? c->chunk_rows : 96, s.rows));
-        const int c6min = std::max(4, std::min(c->chunk_min > 0 ? c->chunk_min : 24, c6max));
-        if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_main, 2, 0, false, s.strips2)) return rc;
-        s.nb_total = std::max(s.nb_total, s.f6_main.units);
-      } else {
-        s.f6_main.units = 0;
-      }
     }
+    if (int rc = deep_geometry(c, s)) return rc;
   }
   return LBM_OK;
 }
@@ -730,11 +765,11 @@ void launch_step4(const lbm_ctx *c, const Step2Args &a0, float *partials3, float
 }
 
 // compact launch set of the three- / four-step kernels: edge units first, then the interior units, one launch
-void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, float *partials, int nlev, hipStream_t st) {
+void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, int units, float *partials, int nlev, hipStream_t st) {
   Step2Args a = a0;
   a.strips = s.strips2;
   a.lanes_out = s.lanes2;
-  const dim3 grid(s.f6_main.units), block(64);
+  const dim3 grid(units), block(64);
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;  // (-1 auto = on)
   if (nt && paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -967,7 +1002,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (batch_kind == KIND_FUSED2) used = s.f_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED3) used = s.f3_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED4) used = s.f4_main.units + (multi ? s.f_edge.units : 0);
-      if (batch_kind == KIND_DEEP) used = s.f6_main.units;
+      if (batch_kind == KIND_DEEP) used = s.f6_main.units + (multi ? s.f6_edge.units : 0);
       if (batch_kind == KIND_MULTI) used = s.m_tiles_x * s.m_tiles_y;
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
@@ -1029,7 +1064,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           a.ty_begin = 0; a.ty_split = s.m_tiles_y; a.ty_begin2 = 0;
           launch_multi(s, a, s.m_tiles_y, s.s_main);
         } else if (kind == KIND_DEEP) {
-          launch_deep(c, s, base_args2(c, s, src, !last, s.f6_main), slot1, adv, s.s_main);
+          launch_deep(c, s, base_args2(c, s, src, !last, s.f6_main), s.f6_main.units, slot1, adv, s.s_main);
         } else if (kind == KIND_FUSED4) {
           Step2Args a = base_args2(c, s, src, !last, s.f4_main);
           a.partials1 = slot1;
@@ -1149,6 +1184,15 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           mm.partials = slot1;
           mm.ty_begin = 1; mm.ty_split = int_trows; mm.ty_begin2 = 0;
           launch_multi(s, mm, int_trows, s.s_main);
+          HIP_TRY(hipGetLastError());
+        }
+      } else if (kind == KIND_DEEP) {
+        Step2Args e = base_args2(c, s, src, !last, s.f6_edge);
+        e.skip_chunk = s.f6_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
+        launch_deep(c, s, e, s.f6_edge.units, slot1 + s.f6_main.units, adv, s_edge);
+        HIP_TRY(hipGetLastError());
+        if (s.f6_main.units > 0) {
+          launch_deep(c, s, base_args2(c, s, src, !last, s.f6_main), s.f6_main.units, slot1, adv, s.s_main);
           HIP_TRY(hipGetLastError());
         }
       } else if (kind == KIND_FUSED4) {
@@ -1307,6 +1351,7 @@ void free_slab(Slab &s) {
   if (s.f3_main.chunk_start) hipFree(s.f3_main.chunk_start);
   if (s.f4_main.chunk_start) hipFree(s.f4_main.chunk_start);
   if (s.f6_main.chunk_start) hipFree(s.f6_main.chunk_start);
+  if (s.f6_edge.chunk_start) hipFree(s.f6_edge.chunk_start);
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
@@ -1629,6 +1674,9 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     // ... slabs of 2M cells and more depth 4 (four-steps-per-launch kernel), the others depth 3 (three-step kernel)
     const bool big = (long)params->nx * rows_min >= (2L << 20);
     c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : (big ? 4 : (rows_min >= 6 ? 3 : 2));
+    // ... and slabs of 5M cells and more depth 8 again: d2q9_deep, up to eight steps per launch set
+    if ((long)params->nx * rows_min >= (5L << 20) && rows_min >= 4 * kDeepSteps && params->nx % 4 == 0 && params->nx >= 256)
+      c->halo_depth = kDeepSteps;
     if (g_defaults.halo_depth > 0) c->halo_depth = g_defaults.halo_depth;
     if (rows_min < 2 * c->halo_depth) c->halo_depth = 2;
   }
@@ -2078,7 +2126,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
   else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
-  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
+  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "halo_sync")) *value = c->halo_sync;
   else if (!strcmp(key, "compact")) *value = compact_sets(c);

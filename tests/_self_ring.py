@@ -37,7 +37,8 @@ code = lbm_amd.TRANSPORTS[transport]
 # the edge tiles push the halo rows themselves) / as edge launch + interior launch + push kernel
 variants = ((0, -1), (1, -1), (2, -1), (0, 0)) if transport == "peer" else ((0, -1),)
 for (sync, compact) in variants:
-    for (fuse, ms) in ((0, 0), (1, 0), (3, 0), (4, 0), (0, 8), (0, 5)):  # 1 / 2 / 3 / 4 / 8 / 5 timesteps per launch set (halo depth 8)
+    # 1 / 2 / 3 / 4 / up to 8 and up to 6 (d2q9_deep) / 8 / 5 (d2q9_multi) timesteps per launch set (halo depth 8)
+    for (fuse, ms) in ((0, 0), (1, 0), (3, 0), (4, 0), (8, 0), (6, 0), (0, 8), (0, 5)):
         kw = dict(rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) if transport == "rccl" else dict(devices=[0])
         with lbm_amd.LBM(p, ob, **kw) as sim:
             assert sim.get_option("transport") == code
@@ -49,7 +50,9 @@ for (sync, compact) in variants:
             if transport == "peer":
                 # compact launch sets exist for the LDS-tile kernel and the three- / four-step kernels (the slab is small:
                 # halo depth 8, so fuse 4 is allowed and used)
-                assert sim.get_option("compact") == (1 if (compact and (ms or fuse >= 3)) else 0)
+                # (d2q9_deep runs as edge launch + interior launch + push kernel)
+                assert sim.get_option("compact") == (1 if (compact and (ms or fuse in (3, 4))) else 0)
+            assert ms or sim.get_option("fuse") == fuse
             sim.upload(cells0)
             sim.run(nsteps)
             got, av = sim.download()   # rank mode: av_vels go through ncclAllReduce

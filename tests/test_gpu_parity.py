@@ -146,9 +146,9 @@ def test_lds_multistep_equals_single_steps(lbm, oracle_f32_omp, nx, ny, T, nstep
 
 def test_default_kernel_choice_by_grid_size(lbm):
     """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel in between, three- and four-step kernels
-    for bandwidth-bound ones, the deep window kernel (up to eight steps per launch) from 8M cells"""
+    for bandwidth-bound ones, the deep window kernel (up to eight steps per launch) from 5M cells"""
     expect = {(128, 128): (8, 0), (256, 256): (8, 0), (512, 512): (8, 0), (768, 512): (0, 1), (1024, 512): (0, 3), (768, 768): (0, 3),
-              (1024, 1024): (0, 3), (1536, 1024): (0, 4), (2048, 1024): (0, 4), (3072, 2048): (0, 4), (4096, 2048): (0, 8), (128, 8192): (0, 0)}
+              (1024, 1024): (0, 3), (1536, 1024): (0, 4), (2048, 1024): (0, 4), (2048, 2048): (0, 4), (3072, 2048): (0, 8), (4096, 2048): (0, 8), (128, 8192): (0, 0)}
     for (nx, ny), (ms, fuse) in expect.items():
         ob = np.zeros((ny, nx), np.int32)
         with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
@@ -305,7 +305,7 @@ def test_transport_self_ring(transport):
     assert "self-ring ok" in r.stdout
 
 
-@pytest.mark.parametrize("world,nx,ny,nsteps,fuse,multistep,sync", [(2, 512, 96, 23, 3, 0, 0), (3, 256, 150, 29, 0, 8, 0),
+@pytest.mark.parametrize("world,nx,ny,nsteps,fuse,multistep,sync", [(2, 512, 96, 23, 3, 0, 0), (2, 512, 96, 23, 8, 0, 0), (3, 256, 150, 29, 0, 8, 0),
                                                                    (4, 2048, 64, 14, 4, 0, 1), (2, 256, 24, 11, 0, 0, 1),
                                                                    (4, 1024, 256, 203, 0, 8, 2), (2, 300, 40, 37, 0, 5, 2),
                                                                    (4, 2048, 256, 30, 4, 0, 2), (3, 1024, 300, 25, 3, 0, 2)])
@@ -346,6 +346,29 @@ def test_row_slabs_four_steps_per_launch(lbm, nslabs, ny, halo_defaults):
         sim.set_option("fuse", 4)
         # slabs thinner than 8 rows fall back to halo depth 2 and the two-step kernel
         assert sim.get_option("fuse") == (4 if ny // nslabs >= 8 else 1)
+        sim.upload(cells0)
+        sim.run(nsteps)
+        many, av_many = sim.download()
+    assert np.array_equal(one, many)
+    assert max_rel(av_many, av_one) < 2e-6
+
+
+@pytest.mark.parametrize("nslabs,nx,ny,depth", [(2, 256, 64, 8), (3, 512, 130, 8), (2, 1024, 260, 6), (4, 260, 200, 7), (5, 256, 160, 8)])
+def test_row_slabs_deep_kernel(lbm, nslabs, nx, ny, depth, halo_defaults):
+    """slabs with halo depth 8 (what slabs of 5M cells and more get) and d2q9_deep on edge + interior launches: bit-identical
+    to one slab; 37 steps = launch sets of 8, 8, 7, 7, 7 (depth 8); a halo depth below the kernel's limit caps the sets"""
+    halo_defaults(halo_depth=8 if depth != 7 else 7)
+    rng = np.random.default_rng(60 + nslabs)
+    nsteps = 37
+    ob, cells0 = random_case(rng, nx, ny)
+    ob[0, :] = 0
+    ob[-1, :] = 0
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob, devices=[0] * nslabs) as sim:
+        sim.set_option("multistep", 0)
+        sim.set_option("fuse", 8 if depth == 7 else depth)
+        assert sim.get_option("fuse") == depth and sim.get_option("halo_depth") == (7 if depth == 7 else 8)
         sim.upload(cells0)
         sim.run(nsteps)
         many, av_many = sim.download()
@@ -463,20 +486,20 @@ def test_partitioned_full_run_passes_checker(tmp_path, mode):
 
 def test_8192x8192_cavity_over_8_slabs_equals_one_slab(lbm):
     """BASELINE config 5's grid, row-partitioned the way an 8-GPU run partitions it (8 slabs of 8192x1024 = 8M cells:
-    halo depth 4, d2q9_step4 on edge and interior launches, peer stores), all on the one GPU: 14 timesteps (three full
-    launch sets + a two-step remainder) bit-identical to the undivided grid"""
+    halo depth 8, d2q9_deep on edge and interior launches, peer stores), all on the one GPU: 19 timesteps (launch sets
+    of 7, 6 and 6 steps) bit-identical to the undivided grid"""
     nx = ny = 8192
     ob = np.zeros((ny, nx), dtype=np.int32)
     ob[0, :] = ob[-1, :] = 1
     ob[:, 0] = ob[:, -1] = 1
-    nsteps = 14
+    nsteps = 19
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     with lbm.LBM(p, ob) as sim:
         sim.upload(None)
         sim.run(nsteps)
         one, av_one = sim.download()
     with lbm.LBM(p, ob, devices=[0] * 8) as sim:
-        assert sim.get_option("nslabs") == 8 and sim.get_option("fuse") == 4 and sim.get_option("halo_depth") == 4
+        assert sim.get_option("nslabs") == 8 and sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8
         assert sim.get_option("transport") == 3
         sim.upload(None)
         sim.run(nsteps)

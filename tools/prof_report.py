@@ -45,7 +45,7 @@ for f in glob.glob(os.path.join(G, "prof_%s_stats" % tag, "*kernel_stats.csv")):
 if not stats:
     sys.exit("no kernel matches %s" % pat)
 kern = stats["name"]
-per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else (4 if "step4" in kern else 3 if "step3" in kern else 2 if "step2" in kern else 8 if "multi" in kern else 1)
+per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else (4 if "step4" in kern else 3 if "step3" in kern else 2 if "step2" in kern else 8 if ("multi" in kern or "deep" in kern) else 1)
 fetch, write, sq, tcc, cal = (counters(n) for n in ("fetch", "write", "sq", "tcc", "calib"))
 fk, wk = mean(fetch, kern, "FETCH_SIZE"), mean(write, kern, "WRITE_SIZE")
 cells = nx * ny
@@ -95,7 +95,7 @@ print("\n".join(lines))
 if fk is not None and "traffic_bytes" in ev and len(sys.argv) > 6 and sys.argv[6] == "traffic":
     tj_path = os.path.join(P, "traffic.json")
     tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-    tj["%dx%d/step%d" % (nx, ny, per_launch)] = {
+    tj["%dx%d/%s" % (nx, ny, "deep" if "deep" in kern else "step%d" % per_launch)] = {
         "hbm_bytes_per_launch": ev["traffic_bytes"], "fetch_size_kib": fk, "write_size_kib": wk,
         "source": "profiles/%s.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of the same bench.py command on %s, FETCH doubled per "
                   "MI355X_MICROARCH.md and checked on a 1 GiB copy)" % (tag, datetime.date.today()),
