@@ -403,6 +403,11 @@ def main():
                 rf["traffic_over_model"] = round(tb / model_bytes, 4)
                 if tj[key].get("evidence"):
                     rf["bound_evidence"] = tj[key]["evidence"]
+                    # `bound` names the roofline `frac` is priced against (the metric's: HBM); which resource the
+                    # kernel actually runs out of first is read off the counters of the committed profile
+                    vs = tj[key]["evidence"].get("valu_issue_share")
+                    if vs is not None:
+                        rf["limited_by"] = "valu_issue" if vs > rf["traffic_frac"] else "hbm"
         # what a plain float4 copy achieves on this box right now (context for `frac`; the spec peak stays `peak`)
         if copy_gbps:
             out["roofline"]["copy_kernel_gbps"] = copy_gbps

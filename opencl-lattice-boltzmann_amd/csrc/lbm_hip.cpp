@@ -232,6 +232,7 @@ struct lbm_ctx {
   int load_bufs = 0;        // d2q9_step3 row-sets of loads in flight: 1, 2, 0 = auto
   int sched_waves = 0;      // waves per SIMD the d2q9_step3 schedule plans for: 1, 2, 0 = auto
   int pair = -1;            // d2q9_step3p (chunk pairs share their start-up rows): 1 on, 0 off, -1 auto
+  int edge_aware = -1;      // d2q9_deep with row slabs: one-round interior schedule whose last units take over the edge launch's slots (-1/1 on, 0 off)
   int obst_paths = -1;      // d2q9_deep: 1 (and -1, auto) = a second collision path without bounce-back selects for waves without blocked cells
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
@@ -494,8 +495,47 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
   e.units_per_band = e.nchunks * s.strips2;
   e.units = e.units_per_band;
   const int i0 = tab[1], i1 = tab[2];
-  if (i1 > i0)
-    if (int rc = fuse_schedule(s, i0, i1, c6max, c6min, true, s.f6_main, 2, 2 * 2 * s.strips2, false, s.strips2)) return rc;
+  if (i1 > i0) {
+    // Edge-aware one-round schedule.  The edge launch goes first and holds 2*strips2 wave slots — but only for
+    // edge_rows + 2(D-1) iterations, a fraction of an interior unit's sweep.  Reserving those slots for the whole launch
+    // set (what the schedules of the other kernels do) made the interior launch of 8192x1024 9 % longer than the
+    // undivided slab's (23 instead of 27 chunks per strip: 290 against 266 us, lbm_run_profiled).  Here every strip gets
+    // n_full chunks of R rows for the slots that are free at once and, as the LAST units of the launch, two shorter
+    // chunks of R - (edge iterations) rows: they are dispatched when the edge units retire and finish with the others.
+    const int slots = 256 * 4 * 2, edge_work = 2 * s.strips2, late_per_strip = 2;
+    const int n_full = (slots - edge_work) / s.strips2;
+    const int rows = i1 - i0, delay = s.edge_rows + 2 * (kDeepSteps - 1);
+    const int R = n_full > 0 ? div_up(rows + late_per_strip * delay, n_full + late_per_strip) : 0;
+    const int r_late = R - delay;
+    if (c->edge_aware != 0 && n_full >= 2 && R <= c6max && r_late >= 4) {
+      std::vector<int> starts;
+      int y = i0, left = rows;
+      for (int k = 0; k < n_full + late_per_strip; k++) {
+        // the late chunks take exactly r_late rows (as far as rows are left); the full ones share the rest evenly
+        const int remaining_full = std::max(0, n_full - k);
+        int sz = k < n_full ? div_up(std::max(0, left - late_per_strip * r_late), std::max(1, remaining_full)) : std::min(r_late, left);
+        if (k == n_full + late_per_strip - 1) sz = left;
+        sz = std::max(0, std::min(sz, left));
+        starts.push_back(y);
+        y += sz;
+        left -= sz;
+      }
+      starts.push_back(i1);
+      FuseGeom &g = s.f6_main;
+      g.nbands = 1;
+      g.nchunks = n_full + late_per_strip;
+      g.units_per_band = g.nchunks * s.strips2;
+      g.units = g.units_per_band;
+      g.single_round = true;
+      g.paired = false;
+      if (g.chunk_start) HIP_TRY(hipFree(g.chunk_start));
+      g.chunk_start = nullptr;
+      if (dev_alloc(&g.chunk_start, starts.size())) return LBM_ERR_HIP;
+      HIP_TRY(hipMemcpy(g.chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
+    } else if (int rc = fuse_schedule(s, i0, i1, c6max, c6min, true, s.f6_main, 2, 2 * edge_work, false, s.strips2)) {
+      return rc;
+    }
+  }
   s.nb_total = std::max(s.nb_total, s.f6_main.units + e.units);
   return LBM_OK;
 }
@@ -2034,6 +2074,12 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     if (value < -1 || value > kDeepSteps || value == 5) return fail(LBM_ERR_ARG, "fuse must be -1 (auto), 0, 1 (or 2), 3, 4 or 6..8");
     c->fuse = (int)value;
     return c->halo_mode ? rebuild_geometry(c) : LBM_OK;
+  }
+  if (!strcmp(key, "edge_aware")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "edge_aware must be -1 (auto), 0 or 1");
+    if (int rc = sync_all(c)) return rc;
+    c->edge_aware = (int)value;
+    return rebuild_geometry(c);
   }
   if (!strcmp(key, "obst_paths")) {
     if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "obst_paths must be -1 (auto), 0 or 1");

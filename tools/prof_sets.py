@@ -18,7 +18,7 @@ for label, ring, extra in (("single slab, no halo rows", False, {}), ("ring of o
             if ring or k != "compact":
                 sim.set_option(k, int(v))
         sim.upload(None); sim.run(64)
-        per = max(sim.get_option("multistep"), {0: 1, 1: 2, 3: 3, 4: 4}[sim.get_option("fuse")])
+        per = max(sim.get_option("multistep"), {0: 1, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[sim.get_option("fuse")])
         st = sim.run_profiled(32 * per)
         ms = sim.run_timed(64 * per)
         print("%-26s %s  unprofiled %.2f us/step = %.0f MLUPS" % (label, {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()},
