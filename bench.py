@@ -313,6 +313,10 @@ def main():
     if args.fuse >= 0:
         sim.set_option("fuse", args.fuse)
     fused = {0: 0, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[sim.get_option("fuse")]   # timesteps per launch of the dominant kernel (0: one)
+    deep = fused >= 6
+    twin = bool(deep and sim.get_option("pair"))   # d2q9_deep_twin (chunk pairs, at most five steps per launch)
+    if deep:
+        fused = sim.get_option("launch_steps")
     multistep = sim.get_option("multistep")
     sim.upload(None)  # uniform rest state, built on the device
     y0, y1 = sim.row_range()
@@ -352,7 +356,7 @@ def main():
         # the dominant kernel advances `steps_per_launch` timesteps of the rank's slab per launch
         steps_per_launch = multistep if multistep else (fused if fused else 1)
         launches = args.steps // steps_per_launch + args.steps % steps_per_launch
-        if fused >= 6 and not multistep and args.steps >= 2:
+        if deep and not multistep and args.steps >= 2:
             # d2q9_deep: the run is split into the fewest launches, of equal depth (20 steps = 7+7+6)
             launches = -(-args.steps // fused)
             steps_per_launch = args.steps / launches
@@ -374,7 +378,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": ("d2q9_multi (%d timesteps per launch on LDS tiles)" % multistep) if multistep else KERNELS[fused],
+                "kernel": ("d2q9_multi (%d timesteps per launch on LDS tiles)" % multistep) if multistep else (
+                    "d2q9_deep%s (up to %d timesteps per launch, lanes of two cells)" % ("_twin" if twin else "", fused) if deep else KERNELS[fused]),
                 "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": round(steps_per_launch, 3),
                 "model_bytes_per_launch": model_bytes,
                 "formula": "achieved = model_bytes_per_launch / launch_us; model_bytes_per_launch = (72 + 1) B x %d cells of the "
@@ -392,7 +397,7 @@ def main():
         if os.path.exists(tp) and world == 1 and not multistep:
             with open(tp) as f:
                 tj = json.load(f)
-            key = "%dx%d/%s" % (nx, ny, "deep" if fused >= 6 else "step%d" % steps_per_launch)
+            key = "%dx%d/%s" % (nx, ny, ("deep_twin" if twin else "deep") if deep else "step%d" % steps_per_launch)
             if key in tj:
                 tb = tj[key]["hbm_bytes_per_launch"]
                 rf = out["roofline"]
@@ -482,11 +487,13 @@ def main():
                 ms2 = s2.run_timed(n2)
                 s2.sync()
                 w2 = time.perf_counter() - t1
-                f2 = {0: 1, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[s2.get_option("fuse")]
+                f2 = s2.get_option("launch_steps")
+                k2 = "d2q9_deep%s" % ("_twin" if s2.get_option("pair") else "") if s2.get_option("fuse") >= 6 else (
+                    "d2q9_multi" if s2.get_option("multistep") else KERNELS[{0: 0, 1: 2, 3: 3, 4: 4}[s2.get_option("fuse")]])
             out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat (both grids fit the 256 MiB Infinity Cache: "
                                        "these bytes come from cache, not HBM — profiles/r02_config3.txt)",
                            "value": round(1024 * 1024 * n2 / w2 / 1e6, 1), "unit": "MLUPS", "steps": n2, "us_per_step": round(ms2 / n2 * 1e3, 3),
-                           "steps_per_launch": f2,
+                           "steps_per_launch": f2, "kernel": k2,
                            "model_gbps": round((BYTES_PER_LU + MASK_BYTES) * 1024 * 1024 / (ms2 * 1e-3 / n2 * f2) / 1e9, 1),
                            "algorithmic_gbps": round(BYTES_PER_LU * 1024 * 1024 / (ms2 * 1e-3 / n2) / 1e9, 1)}
             # reference-rule figures (d2q9-bgk.c:196-263: initial state + step loop + read-back of av_vels and the state)

@@ -1676,16 +1676,27 @@ __device__ __forceinline__ void lds_pair_put(float *p, v2f v) { *reinterpret_cas
 constexpr int deep_halo_lanes(int D) { return D / 2; }           // ceil((D-1)/2) lanes of two cells at either end of a strip
 constexpr int deep_lds_windows(int D) { return D - 1 < 4 ? D - 1 : 4; }  // 4 x 4.5 KB + 1 register window: two waves per SIMD
 
-template <int D, int WL, bool UP, bool NT, bool OBST_PATHS>
+// TWIN (d2q9_deep_twin): the wave is one of the two of a workgroup that work on the chunks 2p (sweeping down) and 2p+1
+// (sweeping up) of one strip and START at their common boundary together — the chunk pairs of section 3.5.  A lone wave
+// primes its windows with L-1 rows beyond the start of its chunk, which are exactly its neighbour's first rows; twins
+// start at their own first row (level l from iteration l on instead of 2l) and write the three planes of their first row
+// of every level that move the twin's way into the trail slots of the TWIN's window of that level, where the twin's
+// ordinary gather finds them one iteration (and one barrier) later.  n + L-1 iterations per chunk instead of n + 2(L-1).
+template <int D, int WL, bool UP, bool NT, bool OBST_PATHS, bool TWIN = false>
 __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, float *lds, float *partials, int pstride, int ys, int ye,
-                                           int xcol, int xhalo_w, int xhalo_e, int lane, bool owner, int unit) {
+                                           int xcol, int xhalo_w, int xhalo_e, int lane, bool owner, int unit,
+                                           const bool twinned_in = false, float *lds_twin = nullptr) {
   // L = timesteps this launch advances (2 .. D, wave-uniform): the run's last launches are shallower.  All row
   // arithmetic is in terms of L; D bounds the unrolled level loop and fixes the halo lanes.
+  static_assert(!TWIN || D - 1 <= WL, "the hand-over of twins goes through LDS windows");
+  const bool twinned = TWIN && twinned_in;  // wave-uniform; a wave whose twin has no rows runs alone
   const size_t ps = a.plane_stride;
   auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
   const int n = ye - ys, d = UP ? 1 : -1;
-  const int r0 = UP ? ys - (L - 1) : ye + (L - 2);  // level 0 works on row r0 + k*d in iteration k = 0 .. n+2(L-1)-1,
-  const int last = n + 2 * (L - 1) - 1;             // level l on row r0 + (k-l)*d from iteration 2l on
+  const int lead = twinned ? 0 : L - 1;     // rows before the chunk's first that level 0 starts with
+  const int sf = twinned ? 1 : 2;           // level l is active from iteration sf*l on
+  const int r0 = UP ? ys - lead : ye - 1 + lead;  // level 0 works on row r0 + k*d in iteration k = 0 .. last,
+  const int last = n + lead + (L - 1) - 1;        // level l on row r0 + (k-l)*d
   float sum[D];
   constexpr int NR = (D - 1 - WL) > 0 ? (D - 1 - WL) : 1;
   PairWindow w[NR];
@@ -1737,8 +1748,8 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
     uint32_t m_top;
     const int row0 = wrap(r0 + k * d);
     accbits = ((accbits << 1) | ((row0 == a.accel_row || row0 == a.accel_row_b) ? 1u : 0u)) & accmask;
-    ownbits = (ownbits << 1) | ((k >= L - 1 && k <= n + L - 2) ? 1u : 0u);
-    if (k >= 2) window_read(1, par, pre[1]);  // issued before level 0's arithmetic: the LDS latency hides behind it
+    ownbits = (ownbits << 1) | ((k >= lead && k <= n + lead - 1) ? 1u : 0u);
+    if (k >= sf) window_read(1, par, pre[1]);  // issued before level 0's arithmetic: the LDS latency hides behind it
     {  // level 0: step t+1 of row0 from the loaded source rows
       v2f g[9];
       g[0] = in.c[0]; g[2] = in.c[2]; g[4] = in.c[4];
@@ -1753,7 +1764,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
       // the wave waits for its loads at the top of the next iteration with the memory counter at zero, stores
       // included — with the stores at the end of an iteration that wait exposed the round trip of stores just issued;
       // now everything it covers was issued a whole iteration of arithmetic earlier.
-      if (k - 1 >= 2 * (L - 1)) store_row(k - 1);
+      if (k - 1 >= sf * (L - 1)) store_row(k - 1);
       // (unconditional: the last iteration loads its own row once more rather than branching around the loads)
       issue_pair_loads<false>(a, wrap(r0 + (k < last ? k + 1 : k) * d), xcol, xhalo_w, xhalo_e, lane, in);
     }
@@ -1762,14 +1773,14 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
       const bool final = (l == D - 1) || (l == L - 1);  // (level l exists: the level before it was not the last)
       v2f nxt[9];
       uint32_t m_nxt = 0;
-      const bool active = k >= 2 * l;
+      const bool active = k >= sf * l;
       const bool in_lds = (l - 1) < WL;
       float *const W = lw + (l - 1) * kPairWinFloats;
       float *const Wp = W + (3 + 3 * par) * kPairSlotFloats;
       PairWindow &R = w[in_lds ? 0 : (l - 1 - WL)];
       if (active) {
         const v2f (&q)[6] = pre[l & 1];
-        if (l + 1 < D && !final && k >= 2 * (l + 1)) window_read(l + 1, par, pre[(l + 1) & 1]);  // the next level's window, early
+        if (l + 1 < D && !final && k >= sf * (l + 1)) window_read(l + 1, par, pre[(l + 1) & 1]);  // the next level's window, early
         v2f g[9];
         g[0] = q[0]; g[1] = q[1]; g[3] = q[2];
         if (UP) {  // the trail row is the row below: its planes 2,5,6 arrive; the newest row is above: 4,7,8
@@ -1805,6 +1816,14 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
         R.S1[0] = UP ? top[2] : top[4]; R.S1[1] = UP ? top[5] : top[8]; R.S1[2] = UP ? top[6] : top[7];
       }
       m_mid[l - 1] = m_top;
+      if (TWIN && twinned && k == l - 1 && in_lds) {
+        // `top` is the first row of level l-1: its planes that move the twin's way become the trail row of the twin's
+        // first gather of level l, next iteration (the twin reads parity l & 1 then; its own puts reach that slot later)
+        float *const Wt = lds_twin + 2 + 2 * lane + (l - 1) * kPairWinFloats + (3 + 3 * (l & 1)) * kPairSlotFloats;
+        lds_pair_put(Wt, UP ? top[4] : top[2]);
+        lds_pair_put(Wt + kPairSlotFloats, UP ? top[8] : top[5]);
+        lds_pair_put(Wt + 2 * kPairSlotFloats, UP ? top[7] : top[6]);
+      }
       if (!active || final) break;
       if (l < D - 1) {
 #pragma unroll
@@ -1812,6 +1831,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
         m_top = m_nxt;
       }
     }
+    if (TWIN && twinned && k <= L - 2) __syncthreads();  // both twins run these iterations; the hand-over of iteration k is read in k+1
   }
   store_row(last);
 #pragma unroll
@@ -1851,6 +1871,44 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
     deep_sweep<D, WL, true, NT, OBST_PATHS>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
   else
     deep_sweep<D, WL, false, NT, OBST_PATHS>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+}
+
+// Chunk pairs of d2q9_deep: a workgroup is two waves, the chunks 2p (down) and 2p+1 (up) of one strip (see deep_sweep).
+// All windows in LDS (D <= 5); units_per_band counts chunk PAIRS x strips.
+template <int D, bool NT, bool OBST_PATHS = false>
+__global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, float *partials, int pstride, int nlev) {
+  constexpr int WL = D - 1, HL = deep_halo_lanes(D);
+  constexpr int kWaveFloats = WL * kPairWinFloats + 4;
+  __shared__ float lds[2 * kWaveFloats];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
+  if (slot >= a.units_per_band) return;
+  const int punit = band * a.units_per_band + slot;
+  const int pair = punit / a.strips, strip = punit - pair * a.strips;
+  const int chunk = 2 * pair + wv;
+  const int unit = chunk * a.strips + strip;
+  const int ys = a.chunk_start[chunk], ye = a.chunk_start[chunk + 1];
+  const int pys = a.chunk_start[chunk ^ 1], pye = a.chunk_start[(chunk ^ 1) + 1];
+  const bool empty = ys >= ye || chunk == a.skip_chunk;
+  const bool twinned = !empty && pys < pye && (chunk ^ 1) != a.skip_chunk;  // the same on both waves
+  if (empty) {
+    if (lane < nlev) partials[(size_t)lane * pstride + unit] = 0.f;
+    return;  // the twin then runs alone and meets no barrier
+  }
+  const int q2 = a.nx >> 1;
+  const int qcol = strip * a.lanes_out + lane - HL;
+  const bool owner = (lane >= HL) && (lane < HL + a.lanes_out) && (qcol < q2);
+  int qw = qcol % q2;
+  if (qw < 0) qw += q2;
+  const int xcol = qw * 2;
+  const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
+  const int xhalo_e = (xcol + 2 >= a.nx) ? 0 : xcol + 2;
+  float *const mine = lds + wv * kWaveFloats, *const theirs = lds + (wv ^ 1) * kWaveFloats;
+  if (wv != 0)  // odd chunks sweep up from their bottom row, even ones down from their top row: twins start together
+    deep_sweep<D, WL, true, NT, OBST_PATHS, true>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
+  else
+    deep_sweep<D, WL, false, NT, OBST_PATHS, true>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
 }
 
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------

@@ -106,6 +106,7 @@ int load_rccl() {
 constexpr bool kStep3LdsDefault = true;   // d2q9_step3 windows in LDS unless option "windows" says otherwise
 constexpr int kDeepSteps = 8;    // most timesteps per launch of d2q9_deep (option fuse = 6..8: the limit of a context)
 constexpr int kDeepMin = 6;
+constexpr int kDeepTwinSteps = 5; // most timesteps per launch of d2q9_deep_twin (chunk pairs: all windows in LDS)
 constexpr int kRingMax = 256;  // most steps of per-workgroup partial sums buffered between reductions
 constexpr int kProfSets = 64, kProfEvents = 5;  // lbm_run_profiled: {edge start, edge end, exchange end, interior start, interior end}
 enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2, TRANSPORT_PEER = 3 };
@@ -171,6 +172,7 @@ struct Slab {
   FuseGeom f4_main;               // schedule of d2q9_step4 (one slab only): long chunks
   FuseGeom f6_main;               // schedule of d2q9_deep: its own strips of two-cell lanes (whole slab, or the interior)
   FuseGeom f6_edge;               // slab mode: its edge schedule {bottom edge rows, (interior), top edge rows}
+  FuseGeom f6_twin;               // one slab: pair schedule of d2q9_deep_twin (used where it is one round of units)
   int strips2 = 0, lanes2 = 0;    // x decomposition of d2q9_deep: strips per row, output lanes (of two cells) per strip
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
@@ -232,6 +234,7 @@ struct lbm_ctx {
   int load_bufs = 0;        // d2q9_step3 row-sets of loads in flight: 1, 2, 0 = auto
   int sched_waves = 0;      // waves per SIMD the d2q9_step3 schedule plans for: 1, 2, 0 = auto
   int pair = -1;            // d2q9_step3p (chunk pairs share their start-up rows): 1 on, 0 off, -1 auto
+  int twin_steps = 0;       // d2q9_deep_twin: most timesteps per launch (2..5), 0 = auto (5)
   int edge_aware = -1;      // d2q9_deep with row slabs: one-round interior schedule whose last units take over the edge launch's slots (-1/1 on, 0 off)
   int obst_paths = -1;      // d2q9_deep: 1 (and -1, auto) = a second collision path without bounce-back selects for waves without blocked cells
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
@@ -302,6 +305,15 @@ bool fuse_possible(const lbm_ctx *c) {
 bool deep_possible(const lbm_ctx *c) {
   return fuse_possible(c) && c->rows_min >= 4 * kDeepSteps && (!c->halo_mode || c->halo_depth >= kDeepMin);
 }
+// d2q9_deep as chunk pairs (d2q9_deep_twin): one slab without halo rows whose pair schedule is one round of units.
+// Same-box A/B (tools/ab.py, GLUPS, best other kernel / twins at five steps per launch): 768x512 88 / 89, 1024x512 97 / 96,
+// 768x768 107 / 122, 1024x768 127 / 138, 1024x1024 140 / 149-152, 1536x1024 168 / 190, 2048x1024 187 / 218, 2048x2048 219-226 /
+// 238-240, 3072x2048 250 / 264; against the lone kernel at eight steps: 8192x1024 265 / 261, 4096x4096 304 / 291, 8192x2048
+// 305 / 290 -> twins below 8M cells.  (Twins at three / four / five steps per launch: 1024x1024 130 / 146 / 149.)
+bool deep_twin_effective(const lbm_ctx *c) {
+  if (c->halo_mode || c->slabs.empty() || !c->slabs[0].f6_twin.paired) return false;
+  return c->pair > 0 || (long)c->p.nx * c->rows_min < (8L << 20);
+}
 // 0 = one launch per step, 2 = d2q9_step2, 3 = d2q9_step3 (falls back to 2 for the last steps of a run and
 // where the halo rows are fewer than 3)
 int fuse_level(const lbm_ctx *c) {
@@ -325,7 +337,8 @@ int fuse_level(const lbm_ctx *c) {
     // as long as the four-step kernel's launch —, 5: 1007, 6: 1113, 7: 1304, 8: 1455 us = 369 GLUPS)
     // (with the band count of a one-round schedule chosen freely, r02: 2048x2048 220 / 222, 3072x2048 232 / 252, 4096x2048
     // 251 / 268, 3072x3072 242 / 272, 4096x4096 270 / 323, 8192x1024 256 / 277, 8192x2048 275 / 317, 8192x8192 293 / 367)
-    if (cells >= 5L << 20 && deep_possible(c)) lvl = kDeepSteps;
+    // ... and, as chunk pairs, from 560K cells (see deep_twin_effective)
+    if (deep_possible(c) && (cells >= 5L << 20 || (cells >= 560L * 1024 && deep_twin_effective(c)))) lvl = kDeepSteps;
   }
   if (lvl > 4 && !(lvl >= kDeepMin && lvl <= kDeepSteps && deep_possible(c))) lvl = 4;
   if (lvl >= kDeepMin && c->halo_mode) lvl = std::min(lvl, c->halo_depth);
@@ -468,7 +481,8 @@ int fuse_schedule_pairs(const lbm_ctx *c, const Slab &s, int r0, int r1, int cma
 // Schedules of d2q9_deep for a slab: lanes of two cells, deep_halo_lanes() of them idle at either end of a strip; strips
 // start on 64-byte boundaries (8 lanes).  2*(D-1) redundant start-up iterations per chunk -> long chunks.
 int deep_geometry(const lbm_ctx *c, Slab &s) {
-  s.f6_main.units = s.f6_edge.units = 0;
+  s.f6_main.units = s.f6_edge.units = s.f6_twin.units = 0;
+  s.f6_twin.paired = false;
   if (!deep_possible(c)) return LBM_OK;
   const int q2 = c->p.nx / 2, lmax = 64 - 2 * lbm::deep_halo_lanes(kDeepSteps);
   s.strips2 = div_up(q2, lmax / 8 * 8);
@@ -478,6 +492,14 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
   if (!c->halo_mode) {
     if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_main, 2, 0, false, s.strips2)) return rc;
     s.nb_total = std::max(s.nb_total, s.f6_main.units);
+    // chunk pairs (d2q9_deep_twin, at most kDeepTwinSteps per launch): where the launch is one round of units
+    s.f6_twin.units = 0;
+    s.f6_twin.paired = false;
+    if (c->pair != 0) {
+      if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_twin, 2, 0, true, s.strips2)) return rc;
+      s.f6_twin.paired = s.f6_twin.single_round || c->pair > 0;
+      if (s.f6_twin.paired) s.nb_total = std::max(s.nb_total, s.f6_twin.units);
+    }
     return LBM_OK;
   }
   // slab mode: the edge launch computes the edge_rows rows at either end of the slab (one chunk each), the interior
@@ -817,6 +839,19 @@ void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, int units
   else hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
 }
 
+void launch_deep_twin(const lbm_ctx *c, const Slab &s, const Step2Args &a0, float *partials, int nlev, hipStream_t st) {
+  Step2Args a = a0;
+  a.strips = s.strips2;
+  a.lanes_out = s.lanes2;
+  a.units_per_band = a0.units_per_band / 2;  // chunk pairs x strips
+  const dim3 grid(s.f6_twin.units / 2), block(128);
+  const bool nt = nt_effective(c), paths = c->obst_paths != 0;
+  if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+}
+
 void launch_compact(int level, bool paired, const Step2Args &a0, float *partials3, float *partials4, int main_units, hipStream_t st) {
   Step2Args a = a0;
   if (paired) {
@@ -1026,6 +1061,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       HIP_TRY(hipEventRecord(s.ev_t0, s.s_main));
     }
 
+  // d2q9_deep as chunk pairs: one slab without halo rows whose pair schedule is one round of units (all slabs alike)
+  const bool deep_twin = fuse_lvl >= kDeepMin && deep_twin_effective(c);
   int batch_first = c->steps_done;
   enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4, KIND_FUSED4 = 5, KIND_DEEP = 6 };
   int batch_kind = KIND_NONE;  // launch kind of the steps buffered in the ring (their slot occupancy differs)
@@ -1042,7 +1079,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (batch_kind == KIND_FUSED2) used = s.f_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED3) used = s.f3_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_FUSED4) used = s.f4_main.units + (multi ? s.f_edge.units : 0);
-      if (batch_kind == KIND_DEEP) used = s.f6_main.units + (multi ? s.f6_edge.units : 0);
+      if (batch_kind == KIND_DEEP) used = deep_twin ? s.f6_twin.units : s.f6_main.units + (multi ? s.f6_edge.units : 0);
       if (batch_kind == KIND_MULTI) used = s.m_tiles_x * s.m_tiles_y;
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
@@ -1076,7 +1113,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       // the remaining steps in as few launches as possible, of equal depth (every launch moves the whole grid once:
       // 20 steps = 7+7+6, not 8+8+4)
       kind = KIND_DEEP;
-      adv = div_up(nsteps - i, div_up(nsteps - i, fuse_lvl));
+      const int cap = deep_twin ? std::min(fuse_lvl, c->twin_steps > 0 ? c->twin_steps : kDeepTwinSteps) : fuse_lvl;
+      adv = div_up(nsteps - i, div_up(nsteps - i, cap));
     } else if (fuse_lvl == 4 && nsteps - i >= 4) {
       kind = KIND_FUSED4;
       adv = 4;
@@ -1104,7 +1142,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           a.ty_begin = 0; a.ty_split = s.m_tiles_y; a.ty_begin2 = 0;
           launch_multi(s, a, s.m_tiles_y, s.s_main);
         } else if (kind == KIND_DEEP) {
-          launch_deep(c, s, base_args2(c, s, src, !last, s.f6_main), s.f6_main.units, slot1, adv, s.s_main);
+          if (deep_twin) launch_deep_twin(c, s, base_args2(c, s, src, !last, s.f6_twin), slot1, adv, s.s_main);
+          else launch_deep(c, s, base_args2(c, s, src, !last, s.f6_main), s.f6_main.units, slot1, adv, s.s_main);
         } else if (kind == KIND_FUSED4) {
           Step2Args a = base_args2(c, s, src, !last, s.f4_main);
           a.partials1 = slot1;
@@ -1392,6 +1431,7 @@ void free_slab(Slab &s) {
   if (s.f4_main.chunk_start) hipFree(s.f4_main.chunk_start);
   if (s.f6_main.chunk_start) hipFree(s.f6_main.chunk_start);
   if (s.f6_edge.chunk_start) hipFree(s.f6_edge.chunk_start);
+  if (s.f6_twin.chunk_start) hipFree(s.f6_twin.chunk_start);
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
@@ -2075,6 +2115,11 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     c->fuse = (int)value;
     return c->halo_mode ? rebuild_geometry(c) : LBM_OK;
   }
+  if (!strcmp(key, "twin_steps")) {
+    if (value != 0 && (value < 2 || value > kDeepTwinSteps)) return fail(LBM_ERR_ARG, "twin_steps must be 0 (auto) or 2..%d", kDeepTwinSteps);
+    c->twin_steps = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "edge_aware")) {
     if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "edge_aware must be -1 (auto), 0 or 1");
     if (int rc = sync_all(c)) return rc;
@@ -2170,8 +2215,13 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
-  else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : (fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
+  else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? deep_twin_effective(c) : fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
+  else if (!strcmp(key, "launch_steps")) {
+    // most timesteps one launch (launch set) of the context's main kernel advances
+    const int ms = multistep_effective(c), lvl = fuse_level(c);
+    *value = ms > 0 ? ms : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, c->twin_steps > 0 ? c->twin_steps : kDeepTwinSteps) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
+  }
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "halo_sync")) *value = c->halo_sync;

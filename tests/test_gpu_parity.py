@@ -146,13 +146,17 @@ def test_lds_multistep_equals_single_steps(lbm, oracle_f32_omp, nx, ny, T, nstep
 
 def test_default_kernel_choice_by_grid_size(lbm):
     """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel in between, three- and four-step kernels
-    for bandwidth-bound ones, the deep window kernel (up to eight steps per launch) from 5M cells"""
-    expect = {(128, 128): (8, 0), (256, 256): (8, 0), (512, 512): (8, 0), (768, 512): (0, 1), (1024, 512): (0, 3), (768, 768): (0, 3),
-              (1024, 1024): (0, 3), (1536, 1024): (0, 4), (2048, 1024): (0, 4), (2048, 2048): (0, 4), (3072, 2048): (0, 8), (4096, 2048): (0, 8), (128, 8192): (0, 0)}
-    for (nx, ny), (ms, fuse) in expect.items():
+    for bandwidth-bound ones, the deep window kernel from 560K cells — as chunk pairs with up to five steps per launch below 8M
+    cells, alone with up to eight above"""
+    expect = {(128, 128): (8, 0, 8), (256, 256): (8, 0, 8), (512, 512): (8, 0, 8), (768, 512): (0, 1, 2), (1024, 512): (0, 3, 3),
+              (768, 768): (0, 8, 5), (1024, 1024): (0, 8, 5), (1536, 1024): (0, 8, 5), (2048, 2048): (0, 8, 5), (3072, 2048): (0, 8, 5),
+              (4096, 2048): (0, 8, 8), (8192, 1024): (0, 8, 8), (128, 8192): (0, 0, 1)}
+    for (nx, ny), (ms, fuse, per_launch) in expect.items():
         ob = np.zeros((ny, nx), np.int32)
         with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
             assert (sim.get_option("multistep"), sim.get_option("fuse") if not ms else 0) == (ms, fuse), (nx, ny)
+            assert sim.get_option("launch_steps") == per_launch, (nx, ny)
+            assert sim.get_option("pair") == (1 if per_launch == 5 else sim.get_option("pair"))
             sim.run(4)  # and it runs
 
 
@@ -744,13 +748,15 @@ def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, 
 @pytest.mark.parametrize("nx,ny,chunk", [(256, 32, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (260, 33, 4), (8192, 32, 8),
                                          (1024, 300, 128), (2048, 130, 0), (1000, 77, 9)])
 @pytest.mark.parametrize("nsteps", [2, 3, 6, 7, 8, 13, 20, 23])
-@pytest.mark.parametrize("depth,obst_paths", [(6, 0), (8, 1), (8, 0), (7, 1)])
-def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, depth, obst_paths):
+@pytest.mark.parametrize("depth,obst_paths,pair", [(6, 0, 0), (8, 1, 0), (8, 0, 1), (7, 1, 1), (8, 1, -1)])
+def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, depth, obst_paths, pair):
     """d2q9_deep (up to eight timesteps per launch; lanes of two cells, explicit packed collision, four LDS windows + up to
     three register windows, x-shifted planes read back from LDS already shifted; obst_paths = 1: a second collision path
     without the bounce-back selects for waves that hold no blocked cell): bit-identical to single steps; a run's steps are
     split into as few launches as possible, of equal depth (20 = 7+7+6: the depth is a launch argument; option fuse = 6..8
-    is its limit), a single left-over step goes to the single-step kernel"""
+    is its limit), a single left-over step goes to the single-step kernel.  pair = 1: d2q9_deep_twin, two waves per
+    workgroup on the chunks 2p / 2p+1 of a strip that start at their common boundary and hand each other their first row
+    of every level (at most five steps per launch: all windows in LDS); -1 = where the library pairs by itself"""
     rng = np.random.default_rng(6 * nx + ny + nsteps)
     ob, cells0 = random_case(rng, nx, ny)
     if obst_paths:
@@ -758,9 +764,11 @@ def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, dept
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     with lbm.LBM(p, ob) as sim:
-        for k, v in {"multistep": 0, "fuse": depth, "chunk_rows": chunk, "obst_paths": obst_paths}.items():
+        for k, v in {"multistep": 0, "fuse": depth, "chunk_rows": chunk, "obst_paths": obst_paths, "pair": pair}.items():
             sim.set_option(k, v)
         assert sim.get_option("fuse") == depth
+        if pair >= 0:
+            assert sim.get_option("pair") == pair
         sim.upload(cells0)
         sim.run(nsteps)
         got, av = sim.download()
