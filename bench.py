@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the nx x ny grid is split over the ranks; weak: every rank gets ny rows")
     ap.add_argument("--accel", type=float, default=0.005)
+    ap.add_argument("--calib-iters", type=int, default=10, help="launches of the 1 GiB copy kernel that measures the roofline denominator")
     ap.add_argument("--fuse", type=int, default=-1, help="timesteps per launch of the register/LDS-window kernels: 0, 1 (= 2), 3, 4, 6..8 (d2q9_deep, at most); -1: library default")
     ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl"],
                     help="N > 1: halo transport(s) to measure; the faster one is `value`")
@@ -325,7 +326,7 @@ def main():
     # also brings the chip to its working clock before the W warm-up steps (the driver's W = 5 is one launch)
     copy_gbps = None
     try:
-        copy_gbps = round(lbm_amd.copy_bandwidth_gbps(1 << 30, 10), 1)
+        copy_gbps = round(lbm_amd.copy_bandwidth_gbps(1 << 30, args.calib_iters), 1)
     except lbm_amd.LBMError:
         pass
 

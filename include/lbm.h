@@ -178,16 +178,20 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  at most that many timesteps per launch: a run is cut into the fewest launches, of equal depth
  *                  (20 steps = 7 + 7 + 6); with row slabs capped by the halo depth (8 for slabs of 5M cells and more);
  *                  falls back to 4 on grids under 32 rows per slab.  0 = one launch per step, -1 = auto (by size: 8
- *                  from 5M cells per slab).
+ *                  from 5M cells per slab; one slab without halo rows: from 560K cells, as chunk pairs below 8M).
+ *   "twin_steps"   chunk-pair form of the deep window kernel ("pair"): most timesteps per launch, 2..8, 0 = auto (5)
+ *   "edge_aware"   deep window kernel with row slabs: -1/1 = one-round interior schedule whose last units take over the
+ *                  wave slots of the edge launch, 0 = slots reserved for the whole launch set
  *   "obst_paths"   deep window kernel: 1 (and -1, auto) = waves that hold no blocked cell take a collision path without
  *                  the bounce-back selects, 0 = one path
  *   "windows"      where the three-step kernel keeps its two windows: 1 = LDS (two waves per SIMD), 0 = registers
  *                  (one wave per SIMD), -1 = auto (1)
  *   "load_bufs"    row-sets of source loads the three-step kernel keeps in flight: 1 or 2, 0 = auto
  *   "sched_waves"  waves per SIMD the three- / four-step kernels' chunk schedule plans for: 1 or 2, 0 = auto
- *   "pair"         chunk-pair form of the three- / four-step kernels (two chunks that start at a common boundary
- *                  run as one workgroup and hand each other their first rows instead of computing them twice):
- *                  1 = always, 0 = never, -1 = auto (where all units of a launch are resident at once)
+ *   "pair"         chunk-pair form of the three- / four-step kernels and of the deep window kernel (two chunks that start
+ *                  at a common boundary run as one workgroup and hand each other their first rows instead of computing
+ *                  them twice): 1 = always, 0 = never, -1 = auto (where all units of a launch are resident at once; the
+ *                  deep window kernel: below 8M cells, one slab without halo rows)
  *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
  *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)
@@ -206,7 +210,8 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "compact"      peer transport + LDS-tile kernel (small slabs): -1/1 = one launch per launch set on one stream, the
  *                  edge tiles store the halo rows into the neighbours themselves; 0 = edge launch / interior launch /
  *                  push kernel on two streams like the larger slabs
- * Read-only through lbm_get_option: "nslabs", "fuse_units", "halo_depth".
+ * Read-only through lbm_get_option: "nslabs", "fuse_units", "halo_depth", "launch_steps" (most timesteps one launch of
+ * the context's main kernel advances).
  */
 int lbm_set_option(lbm_ctx *ctx, const char *key, long value);
 int lbm_get_option(const lbm_ctx *ctx, const char *key, long *value);

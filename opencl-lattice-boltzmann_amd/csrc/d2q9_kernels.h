@@ -1682,13 +1682,15 @@ constexpr int deep_lds_windows(int D) { return D - 1 < 4 ? D - 1 : 4; }  // 4 x 
 // start at their own first row (level l from iteration l on instead of 2l) and write the three planes of their first row
 // of every level that move the twin's way into the trail slots of the TWIN's window of that level, where the twin's
 // ordinary gather finds them one iteration (and one barrier) later.  n + L-1 iterations per chunk instead of n + 2(L-1).
+// Levels whose window lives in registers receive the twin's row through a MAILBOX of three slots behind the wave's
+// windows: written in iteration l-1, read in iteration l (early: with the window reads of the level before), and a
+// barrier at the start of level l keeps the twin's next write (level l+1, later in the same iteration) behind that read.
 template <int D, int WL, bool UP, bool NT, bool OBST_PATHS, bool TWIN = false>
 __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, float *lds, float *partials, int pstride, int ys, int ye,
                                            int xcol, int xhalo_w, int xhalo_e, int lane, bool owner, int unit,
                                            const bool twinned_in = false, float *lds_twin = nullptr) {
   // L = timesteps this launch advances (2 .. D, wave-uniform): the run's last launches are shallower.  All row
   // arithmetic is in terms of L; D bounds the unrolled level loop and fixes the halo lanes.
-  static_assert(!TWIN || D - 1 <= WL, "the hand-over of twins goes through LDS windows");
   const bool twinned = TWIN && twinned_in;  // wave-uniform; a wave whose twin has no rows runs alone
   const size_t ps = a.plane_stride;
   auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
@@ -1717,7 +1719,8 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
   PairLoads in;
   issue_pair_loads<false>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, in);
   // the six window planes level l (1 .. D-1) gathers from: middle row (0, 1 from the west, 3 from the east) and trail row
-  auto window_read = [&](int l, int par, v2f (&q)[6]) __attribute__((always_inline)) {
+  float *const mailbox = lw + WL * kPairWinFloats;  // (twins with register windows only)
+  auto window_read = [&](int l, int par, int k, v2f (&q)[6]) __attribute__((always_inline)) {
     if ((l - 1) < WL) {
       const float *W = lw + (l - 1) * kPairWinFloats;
       const float *Wp = W + (3 + 3 * par) * kPairSlotFloats;
@@ -1727,6 +1730,11 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
       const PairWindow &R = w[(l - 1) < WL ? 0 : (l - 1 - WL)];
       q[0] = R.mid[0]; q[1] = pair_from_west(R.mid[1]); q[2] = pair_from_east(R.mid[2]);
       q[3] = R.S0[0]; q[4] = pair_from_west(R.S0[1]); q[5] = pair_from_east(R.S0[2]);
+      if (TWIN && twinned && k == l) {  // the level's first row: its trail row is the twin's first row
+        q[3] = lds_pair(mailbox);
+        q[4] = lds_pair_shifted(mailbox + kPairSlotFloats - 1);
+        q[5] = lds_pair_shifted(mailbox + 2 * kPairSlotFloats + 1);
+      }
     }
   };
   v2f out[9];  // the last level's row of the previous iteration
@@ -1749,7 +1757,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
     const int row0 = wrap(r0 + k * d);
     accbits = ((accbits << 1) | ((row0 == a.accel_row || row0 == a.accel_row_b) ? 1u : 0u)) & accmask;
     ownbits = (ownbits << 1) | ((k >= lead && k <= n + lead - 1) ? 1u : 0u);
-    if (k >= sf) window_read(1, par, pre[1]);  // issued before level 0's arithmetic: the LDS latency hides behind it
+    if (k >= sf) window_read(1, par, k, pre[1]);  // issued before level 0's arithmetic: the LDS latency hides behind it
     {  // level 0: step t+1 of row0 from the loaded source rows
       v2f g[9];
       g[0] = in.c[0]; g[2] = in.c[2]; g[4] = in.c[4];
@@ -1771,6 +1779,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
 #pragma unroll
     for (int l = 1; l < D; l++) {
       const bool final = (l == D - 1) || (l == L - 1);  // (level l exists: the level before it was not the last)
+      if (TWIN && (l - 1) >= WL && twinned && k == l) __syncthreads();  // mailbox read (above) before the twin's next write
       v2f nxt[9];
       uint32_t m_nxt = 0;
       const bool active = k >= sf * l;
@@ -1780,7 +1789,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
       PairWindow &R = w[in_lds ? 0 : (l - 1 - WL)];
       if (active) {
         const v2f (&q)[6] = pre[l & 1];
-        if (l + 1 < D && !final && k >= sf * (l + 1)) window_read(l + 1, par, pre[(l + 1) & 1]);  // the next level's window, early
+        if (l + 1 < D && !final && k >= sf * (l + 1)) window_read(l + 1, par, k, pre[(l + 1) & 1]);  // the next level's window, early
         v2f g[9];
         g[0] = q[0]; g[1] = q[1]; g[3] = q[2];
         if (UP) {  // the trail row is the row below: its planes 2,5,6 arrive; the newest row is above: 4,7,8
@@ -1816,10 +1825,11 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
         R.S1[0] = UP ? top[2] : top[4]; R.S1[1] = UP ? top[5] : top[8]; R.S1[2] = UP ? top[6] : top[7];
       }
       m_mid[l - 1] = m_top;
-      if (TWIN && twinned && k == l - 1 && in_lds) {
+      if (TWIN && twinned && k == l - 1) {
         // `top` is the first row of level l-1: its planes that move the twin's way become the trail row of the twin's
-        // first gather of level l, next iteration (the twin reads parity l & 1 then; its own puts reach that slot later)
-        float *const Wt = lds_twin + 2 + 2 * lane + (l - 1) * kPairWinFloats + (3 + 3 * (l & 1)) * kPairSlotFloats;
+        // first gather of level l, next iteration (the twin reads parity l & 1 then; its own puts reach that slot later;
+        // a register window: through the twin's mailbox)
+        float *const Wt = lds_twin + 2 + 2 * lane + (in_lds ? (l - 1) * kPairWinFloats + (3 + 3 * (l & 1)) * kPairSlotFloats : WL * kPairWinFloats);
         lds_pair_put(Wt, UP ? top[4] : top[2]);
         lds_pair_put(Wt + kPairSlotFloats, UP ? top[8] : top[5]);
         lds_pair_put(Wt + 2 * kPairSlotFloats, UP ? top[7] : top[6]);
@@ -1874,11 +1884,12 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
 }
 
 // Chunk pairs of d2q9_deep: a workgroup is two waves, the chunks 2p (down) and 2p+1 (up) of one strip (see deep_sweep).
-// All windows in LDS (D <= 5); units_per_band counts chunk PAIRS x strips.
+// units_per_band counts chunk PAIRS x strips.  LDS per wave: the four windows + the mailbox = 19.98 KB: four workgroups
+// (eight waves) still fit a CU.
 template <int D, bool NT, bool OBST_PATHS = false>
 __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, float *partials, int pstride, int nlev) {
-  constexpr int WL = D - 1, HL = deep_halo_lanes(D);
-  constexpr int kWaveFloats = WL * kPairWinFloats + 4;
+  constexpr int WL = deep_lds_windows(D), HL = deep_halo_lanes(D);
+  constexpr int kWaveFloats = WL * kPairWinFloats + (D - 1 > WL ? 3 * kPairSlotFloats : 0) + 4;
   __shared__ float lds[2 * kWaveFloats];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

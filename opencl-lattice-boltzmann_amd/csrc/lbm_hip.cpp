@@ -106,7 +106,10 @@ int load_rccl() {
 constexpr bool kStep3LdsDefault = true;   // d2q9_step3 windows in LDS unless option "windows" says otherwise
 constexpr int kDeepSteps = 8;    // most timesteps per launch of d2q9_deep (option fuse = 6..8: the limit of a context)
 constexpr int kDeepMin = 6;
-constexpr int kDeepTwinSteps = 5; // most timesteps per launch of d2q9_deep_twin (chunk pairs: all windows in LDS)
+constexpr int kDeepTwinSteps = 8; // most timesteps per launch of d2q9_deep_twin (chunk pairs; from 6 on through its mailbox)
+// ... and what it uses unless option twin_steps says otherwise (tools/ab.py, GLUPS at 5 / 6 / 8 steps per launch: 1024x1024
+// 139 / 135 / 131, 2048x2048 234 / 237 / 236, 4096x4096 295 / 302 / 306 — where the lone kernel at 8 steps reaches 314)
+constexpr int kDeepTwinDefault = 5;
 constexpr int kRingMax = 256;  // most steps of per-workgroup partial sums buffered between reductions
 constexpr int kProfSets = 64, kProfEvents = 5;  // lbm_run_profiled: {edge start, edge end, exchange end, interior start, interior end}
 enum { TRANSPORT_AUTO = 0, TRANSPORT_RCCL = 1, TRANSPORT_COPY = 2, TRANSPORT_PEER = 3 };
@@ -234,7 +237,7 @@ struct lbm_ctx {
   int load_bufs = 0;        // d2q9_step3 row-sets of loads in flight: 1, 2, 0 = auto
   int sched_waves = 0;      // waves per SIMD the d2q9_step3 schedule plans for: 1, 2, 0 = auto
   int pair = -1;            // d2q9_step3p (chunk pairs share their start-up rows): 1 on, 0 off, -1 auto
-  int twin_steps = 0;       // d2q9_deep_twin: most timesteps per launch (2..5), 0 = auto (5)
+  int twin_steps = 0;       // d2q9_deep_twin: most timesteps per launch (2..8), 0 = auto (5)
   int edge_aware = -1;      // d2q9_deep with row slabs: one-round interior schedule whose last units take over the edge launch's slots (-1/1 on, 0 off)
   int obst_paths = -1;      // d2q9_deep: 1 (and -1, auto) = a second collision path without bounce-back selects for waves without blocked cells
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
@@ -1113,7 +1116,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       // the remaining steps in as few launches as possible, of equal depth (every launch moves the whole grid once:
       // 20 steps = 7+7+6, not 8+8+4)
       kind = KIND_DEEP;
-      const int cap = deep_twin ? std::min(fuse_lvl, c->twin_steps > 0 ? c->twin_steps : kDeepTwinSteps) : fuse_lvl;
+      const int cap = deep_twin ? std::min(fuse_lvl, c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault) : fuse_lvl;
       adv = div_up(nsteps - i, div_up(nsteps - i, cap));
     } else if (fuse_lvl == 4 && nsteps - i >= 4) {
       kind = KIND_FUSED4;
@@ -2220,7 +2223,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "launch_steps")) {
     // most timesteps one launch (launch set) of the context's main kernel advances
     const int ms = multistep_effective(c), lvl = fuse_level(c);
-    *value = ms > 0 ? ms : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, c->twin_steps > 0 ? c->twin_steps : kDeepTwinSteps) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
+    *value = ms > 0 ? ms : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
   }
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;

@@ -756,7 +756,8 @@ def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, dept
     split into as few launches as possible, of equal depth (20 = 7+7+6: the depth is a launch argument; option fuse = 6..8
     is its limit), a single left-over step goes to the single-step kernel.  pair = 1: d2q9_deep_twin, two waves per
     workgroup on the chunks 2p / 2p+1 of a strip that start at their common boundary and hand each other their first row
-    of every level (at most five steps per launch: all windows in LDS); -1 = where the library pairs by itself"""
+    of every level (five steps per launch by default, up to eight with option twin_steps: the levels whose window lives in
+    registers then receive the twin's row through an LDS mailbox); -1 = where the library pairs by itself"""
     rng = np.random.default_rng(6 * nx + ny + nsteps)
     ob, cells0 = random_case(rng, nx, ny)
     if obst_paths:
@@ -764,7 +765,10 @@ def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, dept
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     with lbm.LBM(p, ob) as sim:
-        for k, v in {"multistep": 0, "fuse": depth, "chunk_rows": chunk, "obst_paths": obst_paths, "pair": pair}.items():
+        opts = {"multistep": 0, "fuse": depth, "chunk_rows": chunk, "obst_paths": obst_paths, "pair": pair}
+        if pair == 1:
+            opts["twin_steps"] = depth   # twins of 7 / 8 steps per launch: the register windows' first rows go through the mailbox
+        for k, v in opts.items():
             sim.set_option(k, v)
         assert sim.get_option("fuse") == depth
         if pair >= 0:
