@@ -20,7 +20,9 @@ def rate(nx, rows, steps, ring):
     with lbm_amd.LBM(p, ob, **kw) as sim:
         sim.upload(None); sim.run(48)
         ms = min(sim.run_timed(steps) for _ in range(3))
-        kern = "multi x%d" % sim.get_option("multistep") if sim.get_option("multistep") else {0: "step", 1: "step2", 3: "step3", 4: "step4"}[sim.get_option("fuse")]
+        f = sim.get_option("fuse")
+        kern = "multi x%d" % sim.get_option("multistep") if sim.get_option("multistep") else (
+            "deep%s x%d" % ("_twin" if sim.get_option("pair") else "", sim.get_option("launch_steps")) if f >= 6 else {0: "step", 1: "step2", 3: "step3", 4: "step4"}[f])
     return ms / steps * 1e3, kern
 
 
