@@ -1542,17 +1542,19 @@ __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *
 // waves per SIMD, so four steps per launch is their limit, and at four steps they move real traffic at 90-93 % of what
 // a copy reaches — only fewer bytes per update make the big grids faster.  This kernel halves the per-wave state
 // instead: a lane holds TWO neighbouring cells (one v2f per plane), a window slot is 512 B, D-1 windows fit
-// (D = 6: four in LDS, 18 KB per wave, one in registers), the grid is read once and written once per D steps.
+// (D = 8: four in LDS, 18 KB per wave, three in registers), the grid is read once and written once per D steps.
 //  - the collision is written on explicit pairs (collide_pair: the operations of collide_cell, in its order, on both
 //    cells at once) and compiles to v_pk_* instructions without the pack/unpack moves the float4 kernels need;
 //  - planes that move along x are read back from the LDS window already shifted by one cell (an unaligned 8-byte read
 //    at +-4 bytes: ds_read2_b32) instead of DPP + moves; a wave runs ONE sweep direction as a template parameter, so
 //    the plane roles are fixed at compile time (no selects) — per cell and step 64 VALU instructions instead of 92;
+//  - the depth is a launch argument (nlev <= D): a run is cut into the fewest launches, of equal depth;
+//  - the last level's row is stored one iteration late, right before that iteration's loads (see deep_sweep);
 //  - what is known about a row (is it the accelerated row, is it one of the chunk's own rows) is computed once, for
 //    level 0, and travels to the deeper levels in scalar shift registers: level l works on the row level 0 had l
 //    iterations earlier.
 // Level l's output is valid from cell l inwards at either end of a strip, so a strip keeps 64 - 2*ceil((D-1)/2) output
-// lanes (58 for D = 6).  Same arithmetic per cell as everything else: bit-identical to D single steps.
+// lanes (56 for D = 8).  Same arithmetic per cell as everything else: bit-identical to D single steps.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat2(float x) { v2f r = {x, x}; return r; }
@@ -1772,6 +1774,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
       // the wave waits for its loads at the top of the next iteration with the memory counter at zero, stores
       // included — with the stores at the end of an iteration that wait exposed the round trip of stores just issued;
       // now everything it covers was issued a whole iteration of arithmetic earlier.
+      // (stores and loads issued BEFORE level 0's arithmetic, right after its gather: 1 % slower everywhere, tools/ab.py --libs)
       if (k - 1 >= sf * (L - 1)) store_row(k - 1);
       // (unconditional: the last iteration loads its own row once more rather than branching around the loads)
       issue_pair_loads<false>(a, wrap(r0 + (k < last ? k + 1 : k) * d), xcol, xhalo_w, xhalo_e, lane, in);

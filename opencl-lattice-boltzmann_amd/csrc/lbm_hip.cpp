@@ -333,7 +333,7 @@ int fuse_level(const lbm_ctx *c) {
     // 2048x2048 183 / 223, 4096x4096 217 / 273, 8192x8192 230 / 295)
     const long cells = (long)c->p.nx * c->rows_min;
     lvl = cells >= 1280L * 1024 ? 4 : (cells > 450L * 1024 ? 3 : 2);
-    // ... and six (d2q9_deep) from 8M cells up on one slab without halo rows (tools/ab.py, four / six steps: 4096x4096
+    // ... and d2q9_deep (first measured at six steps per launch, tools/ab.py, four / six steps: 4096x4096
     // 272 / 272, 8192x1024 244 / 254, 8192x2048 278 / 285, 8192x4096 292 / 317, 6144x6144 276 / 327, 8192x8192 301 / 354,
     // 16384x8192 299 / 362 GLUPS; below: 2048x2048 222 / 227, 1024x1024 137 / 125)
     // (one launch by the steps it advances, 8192x8192, tools/depth_sweep.py: 2..4 steps 940-965 us — the pass over the grid,
