@@ -497,6 +497,24 @@ def main():
                            "steps_per_launch": f2, "kernel": k2,
                            "model_gbps": round((BYTES_PER_LU + MASK_BYTES) * 1024 * 1024 / (ms2 * 1e-3 / n2 * f2) / 1e9, 1),
                            "algorithmic_gbps": round(BYTES_PER_LU * 1024 * 1024 / (ms2 * 1e-3 / n2) / 1e9, 1)}
+            # the HBM-bound members of the kernel family on the same grid, same run: what `frac` looks like for a kernel that IS
+            # bound by the roofline the metric names (the default above trades that for fewer passes over the grid)
+            if deep and (nx, ny) == (8192, 8192):
+                sib = {}
+                for f4, label in ((4, "d2q9_step4"), (0, "d2q9_step")):
+                    per = max(f4, 1)
+                    n4 = 96 if f4 else 24
+                    p4 = lbm_amd.make_params(nx, ny, n4 + 48, 10, 0.1, args.accel, 1.85, obstacles)
+                    with lbm_amd.LBM(p4, obstacles) as s4:
+                        s4.set_option("fuse", f4)
+                        s4.upload(None)
+                        s4.run(48)
+                        ms4 = s4.run_timed(n4)
+                    l4 = ms4 * 1e-3 / (n4 // per)
+                    sib[label] = {"value": round(nx * ny * n4 / ms4 / 1e3, 1), "unit": "MLUPS", "steps_per_launch": per,
+                                  "launch_us": round(l4 * 1e6, 2),
+                                  "frac": round((BYTES_PER_LU + MASK_BYTES) * nx * ny / l4 / 1e9 / HBM_PEAK_GBPS, 4)}
+                out["roofline"]["hbm_bound_siblings"] = sib
             # reference-rule figures (d2q9-bgk.c:196-263: initial state + step loop + read-back of av_vels and the state)
             ref = {}
             p3 = lbm_amd.make_params(nx, ny, args.steps, 10, 0.1, args.accel, 1.85, obstacles)
