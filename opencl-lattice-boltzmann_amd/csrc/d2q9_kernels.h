@@ -1592,7 +1592,8 @@ __device__ __forceinline__ v2f collide_pair(const v2f (&g)[9], bool oa_in, bool 
     out[k].x = oa ? g[opp[k]].x : r.x;
     out[k].y = ob ? g[opp[k]].y : r.y;
   }
-  v2f u = {__builtin_amdgcn_sqrtf(usq.x) * densinv.x, __builtin_amdgcn_sqrtf(usq.y) * densinv.y};
+  const v2f root = {__builtin_amdgcn_sqrtf(usq.x), __builtin_amdgcn_sqrtf(usq.y)};
+  v2f u = root * densinv;
   u.x = oa ? 0.f : u.x;
   u.y = ob ? 0.f : u.y;
   return u;
@@ -1610,12 +1611,12 @@ __device__ __forceinline__ void accelerate_pair(v2f (&f)[9], bool oa, bool ob, f
 // one step on a pair: collision, then the next step's accelerate_flow if this is the accelerated row (the row is the
 // same for the whole wave: a scalar branch).  OBST = false: no cell of the wave is blocked.
 template <bool OBST>
-__device__ __forceinline__ float collide2(const v2f (&g)[9], uint32_t m, float omega, bool accel_uniform, float aw1, float aw2,
-                                          v2f (&o)[9]) {
+__device__ __forceinline__ v2f collide2(const v2f (&g)[9], uint32_t m, float omega, bool accel_uniform, float aw1, float aw2,
+                                        v2f (&o)[9]) {
   const bool oa = (m & 0xffu) != 0, ob = (m & 0xff00u) != 0;
   const v2f u = collide_pair<OBST>(g, oa, ob, omega, o);
   if (accel_uniform) accelerate_pair(o, OBST && oa, OBST && ob, aw1, aw2);
-  return u.x + u.y;
+  return u;  // |j|/rho of the two cells (0 for a blocked one): summed per component, the components added at the end
 }
 
 // the pair shifted by one cell: lane i receives the odd cell of lane i-1 / the even cell of lane i+1
@@ -1701,12 +1702,12 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
   const int sf = twinned ? 1 : 2;           // level l is active from iteration sf*l on
   const int r0 = UP ? ys - lead : ye - 1 + lead;  // level 0 works on row r0 + k*d in iteration k = 0 .. last,
   const int last = n + lead + (L - 1) - 1;        // level l on row r0 + (k-l)*d
-  float sum[D];
+  v2f sum[D];
   constexpr int NR = (D - 1 - WL) > 0 ? (D - 1 - WL) : 1;
   PairWindow w[NR];
   uint32_t m_mid[D - 1];
 #pragma unroll
-  for (int l = 0; l < D; l++) sum[l] = 0.f;
+  for (int l = 0; l < D; l++) sum[l] = splat2(0.f);
 #pragma unroll
   for (int l = 0; l < D - 1; l++) m_mid[l] = 0;
 #pragma unroll
@@ -1766,7 +1767,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
       g[1] = pair_from_west(in.c[1], in.h0); g[5] = pair_from_west(in.c[5], in.h1); g[8] = pair_from_west(in.c[8], in.h2);
       g[3] = pair_from_east(in.c[3], in.h0); g[6] = pair_from_east(in.c[6], in.h1); g[7] = pair_from_east(in.c[7], in.h2);
       m_top = in.m >> mask_shift;  // (bits 16.. may hold the neighbouring pair's bytes: every test masks)
-      float t;
+      v2f t;
       if (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_top & 0xffffu) != 0) == 0ull) t = collide2<false>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
       else t = collide2<true>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
       if ((ownbits & 1u) && owner) sum[0] += t;
@@ -1804,7 +1805,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
         }
         m_nxt = m_mid[l - 1];
         const bool acc = ((accbits >> l) & 1u) != 0;
-        float t;
+        v2f t;
         if (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_nxt & 0xffffu) != 0) == 0ull) t = collide2<false>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
         else t = collide2<true>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
         if (!final) {
@@ -1850,7 +1851,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
 #pragma unroll
   for (int l = 0; l < D; l++) {
     if (l >= L) break;
-    const float s = wave_sum(sum[l]);
+    const float s = wave_sum(sum[l].x + sum[l].y);
     if (lane == 0) partials[(size_t)l * pstride + unit] = s;
   }
 }
