@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the nx x ny grid is split over the ranks; weak: every rank gets ny rows")
     ap.add_argument("--accel", type=float, default=0.005)
+    ap.add_argument("--valu-calib", type=int, default=40, help="launches (~1 ms each) of the packed-FMA issue-rate calibration; 0 = skip")
     ap.add_argument("--calib-iters", type=int, default=10, help="launches of the 1 GiB copy kernel that measures the roofline denominator")
     ap.add_argument("--fuse", type=int, default=-1, help="timesteps per launch of the register/LDS-window kernels: 0, 1 (= 2), 3, 4, 6..8 (d2q9_deep, at most); -1: library default")
     ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl"],
@@ -324,9 +325,13 @@ def main():
 
     # the roofline denominator first (a float4 copy of 1 GiB each way, ~10 launches): measured anyway, and done here it
     # also brings the chip to its working clock before the W warm-up steps (the driver's W = 5 is one launch)
-    copy_gbps = None
+    copy_gbps = valu_tera = None
     try:
         copy_gbps = round(lbm_amd.copy_bandwidth_gbps(1 << 30, args.calib_iters), 1)
+        # ... and the denominator of the kernels that are bound by instruction issue (d2q9_deep): packed-FMA issue rate,
+        # ~1 ms per launch.  Like the copies, this also loads the chip before the warm-up steps (profiles/r02_cold_start.txt).
+        if args.valu_calib > 0:
+            valu_tera = round(lbm_amd.valu_rate_tera(args.valu_calib), 2)
     except lbm_amd.LBMError:
         pass
 
@@ -415,6 +420,14 @@ def main():
                     if vs is not None:
                         rf["limited_by"] = "valu_issue" if vs > rf["traffic_frac"] else "hbm"
         # what a plain float4 copy achieves on this box right now (context for `frac`; the spec peak stays `peak`)
+        if valu_tera:
+            # issue-rate roofline: VALU lane-instructions the kernel executes per lattice update (committed profile) x rate
+            lane = (out["roofline"].get("bound_evidence") or {}).get("valu_lane_instr_per_cell_step")
+            out["roofline"]["valu"] = {"issue_rate_measured": valu_tera, "unit": "1e12 packed-fp32 lane-instructions/s",
+                                       "theoretical": 39.3,
+                                       "lane_instr_per_cell_step": lane, "lane_instr_source": "SQ_INSTS_VALU of the committed profile" if lane else None,
+                                       "achieved": round(lane * lups / 1e12, 2) if lane else None,
+                                       "frac": round(lane * lups / 1e12 / valu_tera, 4) if lane else None}
         if copy_gbps:
             out["roofline"]["copy_kernel_gbps"] = copy_gbps
             out["roofline"]["frac_of_copy_kernel"] = round(achieved / copy_gbps, 4)

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(PKG_DIR, os.environ.get("LBM_LIB", "liblbm_hip.so"))  # 
 ABI_SYMBOLS = [
     "lbm_create", "lbm_create_rank", "lbm_comm_id_size", "lbm_comm_get_id", "lbm_upload", "lbm_run",
     "lbm_run_timed", "lbm_sync", "lbm_download", "lbm_steps_done", "lbm_row_range", "lbm_final_state",
-    "lbm_reynolds", "lbm_set_option", "lbm_get_option", "lbm_copy_bandwidth", "lbm_destroy",
+    "lbm_reynolds", "lbm_set_option", "lbm_get_option", "lbm_copy_bandwidth", "lbm_valu_rate", "lbm_destroy",
     "lbm_last_error", "lbm_version", "lbm_set_default", "lbm_peer_info_size", "lbm_peer_info", "lbm_connect_peers",
     "lbm_run_profiled",
 ]
@@ -78,6 +78,7 @@ def load_library():
     L.lbm_set_option.argtypes = [vp, cp, ctypes.c_long]
     L.lbm_get_option.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_long)]
     L.lbm_copy_bandwidth.argtypes = [ctypes.c_size_t, ci, ctypes.POINTER(ctypes.c_double)]
+    L.lbm_valu_rate.argtypes = [ci, ctypes.POINTER(ctypes.c_double)]
     L.lbm_set_default.argtypes = [cp, ctypes.c_long]
     L.lbm_peer_info_size.restype = ctypes.c_size_t
     L.lbm_peer_info.argtypes = [vp, vp]
@@ -154,6 +155,13 @@ def accel_row_local(ny, y0, rows):
     """local index of the accelerated global row ny-2 (kernels.cl:18) inside a slab, or -1."""
     ar = ny - 2
     return ar - y0 if y0 <= ar < y0 + rows else -1
+
+
+def valu_rate_tera(launches=40):
+    """issue rate of packed fp32 FMAs in 1e12 lane-instructions per second (the roofline of the issue-bound kernels)"""
+    g = ctypes.c_double(0.0)
+    _check(load_library().lbm_valu_rate(launches, ctypes.byref(g)), "lbm_valu_rate")
+    return g.value
 
 
 def copy_bandwidth_gbps(nbytes=1 << 30, iters=20):

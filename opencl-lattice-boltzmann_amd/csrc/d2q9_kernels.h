@@ -2214,6 +2214,26 @@ __global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsig
 }
 
 // ---- roofline denominator: float4 streaming copy ---------------------------------------------
+// VALU roofline calibration: eight independent chains of packed fp32 fused multiply-adds per thread — the instruction the
+// deep window kernel's collision is made of — so that the issue rate, not a dependency, bounds the loop.
+__global__ __launch_bounds__(kBlock) void valu_spin(float *out, int iters, float seed) {
+  v2f acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = splat2(seed + 0.125f * (float)i + 1e-3f * (float)(threadIdx.x & 7));
+  const v2f a = splat2(0.99990f), b = splat2(1.0e-4f);
+  for (int k = 0; k < iters; k++) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] = fma2(acc[i], a, b);
+    }
+  }
+  v2f s = acc[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++) s += acc[i];
+  out[(size_t)blockIdx.x * kBlock + threadIdx.x] = s.x + s.y;
+}
+
 __global__ __launch_bounds__(kBlock) void copy_f4(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = in[i];
 }

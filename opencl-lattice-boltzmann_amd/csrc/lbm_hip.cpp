@@ -2235,6 +2235,30 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   return LBM_OK;
 }
 
+int lbm_valu_rate(int launches, double *tera_lane_instr_per_s) {
+  if (!tera_lane_instr_per_s || launches < 1) return fail(LBM_ERR_ARG, "bad argument");
+  // 8 workgroups of 256 threads per CU: eight waves per SIMD, each with eight independent chains
+  const int nb = 256 * 8, iters = 4096;  // 4 x 8 packed FMAs per loop iteration: 131072 per thread and launch (~1 ms)
+  float *out = nullptr;
+  HIP_TRY(hipMalloc((void **)&out, (size_t)nb * kBlock * sizeof(float)));
+  hipEvent_t t0, t1;
+  hipEventCreate(&t0);
+  hipEventCreate(&t1);
+  hipLaunchKernelGGL(lbm::valu_spin, dim3(nb), dim3(kBlock), 0, 0, out, iters, 0.5f);  // warm-up
+  hipEventRecord(t0, 0);
+  for (int i = 0; i < launches; i++) hipLaunchKernelGGL(lbm::valu_spin, dim3(nb), dim3(kBlock), 0, 0, out, iters, 0.5f);
+  hipEventRecord(t1, 0);
+  const hipError_t e = hipEventSynchronize(t1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, t0, t1);
+  hipEventDestroy(t0);
+  hipEventDestroy(t1);
+  hipFree(out);
+  if (e != hipSuccess || ms <= 0.f) return fail(LBM_ERR_HIP, "valu_spin: %s", hipGetErrorString(e));
+  *tera_lane_instr_per_s = (double)nb * kBlock * (double)iters * 32.0 * launches / (ms * 1e-3) / 1e12;
+  return LBM_OK;
+}
+
 int lbm_copy_bandwidth(size_t bytes, int iters, double *gbps) {
   if (!gbps || iters < 1 || bytes < 16) return fail(LBM_ERR_ARG, "bad argument");
   const size_t n = bytes / 16;

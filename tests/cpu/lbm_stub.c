@@ -89,6 +89,7 @@ int lbm_reynolds(lbm_ctx *c, float *re) { (void)c; *re = 1.0f; return LBM_OK; }
 int lbm_set_option(lbm_ctx *c, const char *k, long v) { (void)c; (void)k; (void)v; return LBM_OK; }
 int lbm_get_option(const lbm_ctx *c, const char *k, long *v) { (void)c; (void)k; *v = 0; return LBM_OK; }
 int lbm_copy_bandwidth(size_t b, int it, double *g) { (void)b; (void)it; *g = 0.0; return LBM_OK; }
+int lbm_valu_rate(int n, double *g) { (void)n; *g = 0.0; return LBM_OK; }
 void lbm_destroy(lbm_ctx *c)
 {
   if (!c) return;

@@ -83,6 +83,7 @@ if mean(sq, kern, "SQ_WAVE_CYCLES"):
         share = g("SQ_INSTS_VALU") * 4.0 / (1024.0 * dur_cycles) if dur_cycles else 0.0
         lines.append("    VALU issue slots used: %.0f %% (VALU wave-instructions x 4 cycles / (1024 SIMDs x %.3g cycles of the launch))" % (100 * share, dur_cycles))
         ev["valu_issue_share"] = round(share, 3)
+        ev["valu_lane_instr_per_cell_step"] = round(g("SQ_INSTS_VALU") * 64.0 / (cells * per_launch), 1)
     ev["wave_time_issuing"] = round(g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"), 3)
     ev["wave_time_waitcnt"] = round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 3)
 if mean(tcc, kern, "TCC_HIT_sum") is not None:
