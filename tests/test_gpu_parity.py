@@ -609,6 +609,12 @@ def test_y_extension_invariance_16384x16384(lbm):
         assert np.array_equal(res[ny][2], res[ny][3])
 
 
+def test_calibration_kernels(lbm):
+    """the two roofline denominators of bench.py: float4 copy bandwidth and packed-FMA issue rate, both plausible for an MI355X"""
+    assert 2000.0 < lbm.copy_bandwidth_gbps(1 << 28, 4) < 8000.0
+    assert 10.0 < lbm.valu_rate_tera(4) < 45.0
+
+
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` (small grid here)"""
     import json
@@ -633,6 +639,9 @@ def test_bench_json_contract():
     assert abs(rf["achieved"] - rf["model_bytes_per_launch"] / (rf["launch_us"] * 1e-6) / 1e9) / rf["achieved"] < 0.01
     alg = rf["algorithmic"]
     assert abs(alg["gbps"] - 72.0 * 1024 * 1024 * rf["steps_per_launch"] / (rf["launch_us"] * 1e-6) / 1e9) / alg["gbps"] < 0.01
+    # the issue-rate roofline of the deep window kernel: measured packed-FMA rate, lane-instructions per update from the profile
+    va = rf["valu"]
+    assert 5.0 < va["issue_rate_measured"] <= va["theoretical"] * 1.1 and (va["frac"] is None or 0.0 < va["frac"] < 1.0)
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1 and cb["unit"] == "MLUPS" and cb["sample"]
     # BASELINE config 1 (128x128 on the serial CPU path, full length, through the checker) and the 1024x1024 rates
