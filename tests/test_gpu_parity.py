@@ -309,7 +309,7 @@ def test_transport_self_ring(transport):
     assert "self-ring ok" in r.stdout
 
 
-@pytest.mark.parametrize("world,nx,ny,nsteps,fuse,multistep,sync", [(2, 512, 96, 23, 3, 0, 0), (2, 512, 96, 23, 8, 0, 0), (3, 256, 150, 29, 0, 8, 0),
+@pytest.mark.parametrize("world,nx,ny,nsteps,fuse,multistep,sync", [(2, 512, 96, 23, 3, 0, 0), (2, 512, 96, 23, 8, 0, 0), (4, 2048, 256, 30, 8, 0, 0), (3, 256, 150, 29, 0, 8, 0),
                                                                    (4, 2048, 64, 14, 4, 0, 1), (2, 256, 24, 11, 0, 0, 1),
                                                                    (4, 1024, 256, 203, 0, 8, 2), (2, 300, 40, 37, 0, 5, 2),
                                                                    (4, 2048, 256, 30, 4, 0, 2), (3, 1024, 300, 25, 3, 0, 2)])
