@@ -177,6 +177,7 @@ struct Slab {
   FuseGeom f6_edge;               // slab mode: its edge schedule {bottom edge rows, (interior), top edge rows}
   FuseGeom f6_twin;               // one slab: pair schedule of d2q9_deep_twin (used where it is one round of units)
   int strips2 = 0, lanes2 = 0;    // x decomposition of d2q9_deep: strips per row, output lanes (of two cells) per strip
+  int strips_tw = 0, lanes_tw = 0;  // ... of d2q9_deep_twin: at up to five steps per launch two halo lanes per side are enough
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
   int m_tx = 32, m_ty = 16;          // its tile size (chosen by how many tiles the slab gives)
@@ -499,7 +500,19 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     s.f6_twin.units = 0;
     s.f6_twin.paired = false;
     if (c->pair != 0) {
-      if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_twin, 2, 0, true, s.strips2)) return rc;
+      // Twins of up to five steps per launch run the D = 5 instantiation: 2 halo lanes per side instead of 4, strips of up
+      // to 60 lanes (starts on 32-byte boundaries: these grids live in the caches).  1024x1024: 9 strips instead of 10 (the
+      // tenth held 8 useful lanes), 226 chunks of 4.5 rows instead of 172 of 6.
+      const int tw_cap = c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault;
+      if (tw_cap <= kDeepTwinDefault) {
+        const int lmax5 = 64 - 2 * lbm::deep_halo_lanes(kDeepTwinDefault);
+        s.strips_tw = div_up(q2, lmax5 / 4 * 4);
+        s.lanes_tw = std::min(lmax5, (div_up(q2, s.strips_tw) + 3) / 4 * 4);
+      } else {
+        s.strips_tw = s.strips2;
+        s.lanes_tw = s.lanes2;
+      }
+      if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_twin, 2, 0, true, s.strips_tw)) return rc;
       s.f6_twin.paired = s.f6_twin.single_round || c->pair > 0;
       if (s.f6_twin.paired) s.nb_total = std::max(s.nb_total, s.f6_twin.units);
     }
@@ -844,11 +857,19 @@ void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, int units
 
 void launch_deep_twin(const lbm_ctx *c, const Slab &s, const Step2Args &a0, float *partials, int nlev, hipStream_t st) {
   Step2Args a = a0;
-  a.strips = s.strips2;
-  a.lanes_out = s.lanes2;
+  a.strips = s.strips_tw;
+  a.lanes_out = s.lanes_tw;
   a.units_per_band = a0.units_per_band / 2;  // chunk pairs x strips
   const dim3 grid(s.f6_twin.units / 2), block(128);
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;
+  if ((c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault) <= kDeepTwinDefault) {
+    // all windows in LDS, no mailbox, 2 halo lanes per side
+    if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+    else if (nt) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+    else if (paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+    else hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+    return;
+  }
   if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -2120,8 +2141,9 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   }
   if (!strcmp(key, "twin_steps")) {
     if (value != 0 && (value < 2 || value > kDeepTwinSteps)) return fail(LBM_ERR_ARG, "twin_steps must be 0 (auto) or 2..%d", kDeepTwinSteps);
+    if (int rc = sync_all(c)) return rc;
     c->twin_steps = (int)value;
-    return LBM_OK;
+    return rebuild_geometry(c);  // (the strips of the twins depend on it)
   }
   if (!strcmp(key, "edge_aware")) {
     if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "edge_aware must be -1 (auto), 0 or 1");
