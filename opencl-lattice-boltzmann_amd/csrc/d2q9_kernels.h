@@ -1858,18 +1858,71 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
 
 // nlev = timesteps the launch advances (2 .. D); partials: [nlev][pstride], slot l*pstride + unit = the unit's sum of
 // |j|/rho after step t+1+l
-template <int D, bool NT, bool OBST_PATHS = false>
+// An edge unit's output rows a second time, into the ring neighbour's halo rows (push_chunk for lanes of two cells: one
+// 8-byte write-through store per plane and lane).
+__device__ __forceinline__ void push_chunk_pairs(const Step2Args *la, int ys, int ye, int xcol, bool owner) {
+  drain_stores();
+  const HaloPeer *pp = uniform_ptr(la->peer);
+  const int hi0 = __builtin_amdgcn_readfirstlane(pp->row_hi0);
+  const int lo0 = __builtin_amdgcn_readfirstlane(pp->row_lo0);
+  const int rows = __builtin_amdgcn_readfirstlane(pp->push_rows);
+  const int buf = __builtin_amdgcn_readfirstlane(la->peer_buf) & 1;
+  const int side = ys >= hi0 ? 1 : 0;
+  const int base = side ? hi0 : lo0;
+  if (ys < base || ye > base + rows) {
+    if ((threadIdx.x & 63) == 0) atomicOr(pp->wait_err, 2u);
+    return;
+  }
+  const size_t rs = la->row_stride, ps = la->plane_stride;
+  const float *own = la->dst + xcol;
+  float *peer = pp->push[side][buf] + xcol;
+  if (owner) {
+    for (int y = ys; y < ye; y++) {
+      const float *src = own + (size_t)y * rs;
+      float *dst = peer + (size_t)(y - base) * rs;
+      v2f v[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) v[k] = *reinterpret_cast<const v2f *>(src + k * ps);
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        global_u64 *q = (global_u64 *)(unsigned long long)(dst + k * ps);
+        const unsigned long long bits = ((unsigned long long)__float_as_uint(v[k].y) << 32) | __float_as_uint(v[k].x);
+        __hip_atomic_store(q, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  drain_stores();
+}
+
+// PUSH: the kernel as ONE launch per launch set of a slab (compact launch sets, see Step2Args): the first edge_units
+// workgroups work through the edge schedule, push their rows into the ring neighbours and raise the flag words.
+template <int D, bool NT, bool OBST_PATHS = false, bool PUSH = false>
 __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *partials, int pstride, int nlev) {
   constexpr int WL = deep_lds_windows(D), HL = deep_halo_lanes(D);
   __shared__ float lds[WL * kPairWinFloats + 4];
   const int lane = threadIdx.x;
-  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
-  if (slot >= a.units_per_band) return;
-  const int unit = band * a.units_per_band + slot;
-  const int chunk = unit / a.strips, strip = unit - chunk * a.strips;
-  const int ys = a.chunk_start[chunk], ye = a.chunk_start[chunk + 1];
-  if (ys >= ye || chunk == a.skip_chunk) {
+  const UnitSel us = select_unit<PUSH>(a, a.edge_units);
+  const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  if constexpr (PUSH) {
+    // in-kernel wait for the neighbours' halo rows (halo_sync = 2): every edge wave for itself, before its first load
+    if (us.edge && (a.peer_mode & 2)) {
+      const Step2Args *la = late_args<Step2Args>();
+      const HaloPeer *pp = la->peer;
+      if (lane < 2) spin_on_flag(pp->wait_flags + lane, la->wait_seq, pp->wait_err, pp->wait_ticks);
+    }
+  }
+  const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
+  if (slot >= us.units_per_band) return;
+  const int unit0 = band * us.units_per_band + slot;
+  const int chunk = unit0 / a.strips, strip = unit0 - chunk * a.strips;
+  const int unit = unit0 + us.partial_off;  // slot of the velocity sums
+  const int ys = us.chunk_start[chunk], ye = us.chunk_start[chunk + 1];
+  if (ys >= ye || chunk == us.skip) {
     if (lane < nlev) partials[(size_t)lane * pstride + unit] = 0.f;
+    if constexpr (PUSH) {
+      const Step2Args *la = late_args<Step2Args>();
+      if (us.edge && (la->peer_mode & 1)) publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
     return;
   }
   const int q2 = a.nx >> 1;
@@ -1885,6 +1938,13 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
     deep_sweep<D, WL, true, NT, OBST_PATHS>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
   else
     deep_sweep<D, WL, false, NT, OBST_PATHS>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+  if constexpr (PUSH) {
+    const Step2Args *la = late_args<Step2Args>();
+    if (do_push) {
+      push_chunk_pairs(la, ys, ye, xcol, owner);
+      publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
+  }
 }
 
 // Chunk pairs of d2q9_deep: a workgroup is two waves, the chunks 2p (down) and 2p+1 (up) of one strip (see deep_sweep).

@@ -375,6 +375,7 @@ bool compact_sets(const lbm_ctx *c) {
   if (!c->halo_mode || c->transport_eff != TRANSPORT_PEER || c->compact == 0) return false;
   if (multistep_effective(c) > 0) return true;
   const int lvl = fuse_level(c);
+  if (lvl >= kDeepMin) return true;  // d2q9_deep<.., PUSH>
   return (lvl == 3 || lvl == 4) && windows_in_lds(c) && step3_load_bufs(c) == 1 && c->nt_loads <= 0;
 }
 
@@ -855,6 +856,19 @@ void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, int units
   else hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
 }
 
+// compact launch set of d2q9_deep: the edge units first, then the interior units, ONE launch
+void launch_deep_compact(const lbm_ctx *c, const Slab &s, const Step2Args &a0, float *partials, int nlev, hipStream_t st) {
+  Step2Args a = a0;
+  a.strips = s.strips2;
+  a.lanes_out = s.lanes2;
+  const dim3 grid(a0.edge_units + s.f6_main.units), block(64);
+  const bool nt = nt_effective(c), paths = c->obst_paths != 0;
+  if (nt && paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+}
+
 void launch_deep_twin(const lbm_ctx *c, const Slab &s, const Step2Args &a0, float *partials, int nlev, hipStream_t st) {
   Step2Args a = a0;
   a.strips = s.strips_tw;
@@ -1223,6 +1237,32 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         if (int rc = mark(s, 4, s.s_main)) return rc;
         continue;
       }
+      if (compact && kind == KIND_DEEP) {
+        // ---- compact launch set of d2q9_deep: as for the three- / four-step kernels below
+        if (c->halo_sync != 2)
+          if (int rc = wait_halos(c, s, s.s_main, c->halo_seq)) return rc;
+        Step2Args a = base_args2(c, s, src, !last, s.f6_main);
+        a.edge_chunk_start = s.f6_edge.chunk_start;
+        a.edge_nchunks = s.f6_edge.nchunks;
+        a.edge_units = s.f6_edge.units;
+        a.edge_skip = s.f6_edge.skip;
+        a.edge_partial_off = s.f6_main.units;
+        a.peer = s.d_peer;
+        if (c->halo_sync == 2) {
+          a.peer_mode |= 2;
+          a.wait_seq = c->halo_seq;
+        }
+        if (!last) {
+          a.peer_mode |= 1;
+          a.peer_buf = src ^ 1;
+          a.seq = c->halo_seq + 1;
+        }
+        if (int rc = mark(s, 3, s.s_main)) return rc;
+        launch_deep_compact(c, s, a, slot1, adv, s.s_main);
+        HIP_TRY(hipGetLastError());
+        if (int rc = mark(s, 4, s.s_main)) return rc;
+        continue;
+      }
       if (compact && (kind == KIND_FUSED4 || kind == KIND_FUSED3)) {
         // ---- compact launch set of the window kernels: wait for the neighbours' rows of the latest exchange, then ONE
         // launch — the edge chunks first (they push this set's halo rows and raise the flags), then the interior chunks
@@ -1365,7 +1405,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (int rc = mark(s, 1, s_edge)) return rc;
       if (int rc = mark(s, 4, s.s_main)) return rc;
     }
-    if (multi && compact && (kind == KIND_MULTI || kind == KIND_FUSED3 || kind == KIND_FUSED4)) {
+    if (multi && compact && (kind == KIND_MULTI || kind == KIND_FUSED3 || kind == KIND_FUSED4 || kind == KIND_DEEP)) {
       if (!last) c->halo_seq++;     // the edge units of this set's launches have pushed exchange number halo_seq
     } else if (multi) {
       if (!last)

@@ -48,10 +48,9 @@ for (sync, compact) in variants:
             sim.set_option("fuse", fuse)
             sim.set_option("multistep", ms)
             if transport == "peer":
-                # compact launch sets exist for the LDS-tile kernel and the three- / four-step kernels (the slab is small:
-                # halo depth 8, so fuse 4 is allowed and used)
-                # (d2q9_deep runs as edge launch + interior launch + push kernel)
-                assert sim.get_option("compact") == (1 if (compact and (ms or fuse in (3, 4))) else 0)
+                # compact launch sets exist for the LDS-tile kernel, the three- / four-step kernels and d2q9_deep (the slab is
+                # small: halo depth 8, so fuse 4 and fuse 8 are allowed and used)
+                assert sim.get_option("compact") == (1 if (compact and (ms or fuse >= 3)) else 0)
             assert ms or sim.get_option("fuse") == fuse
             sim.upload(cells0)
             sim.run(nsteps)
