@@ -207,9 +207,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "halo_sync"    peer transport, consumer side: 0 = wait kernel with a bounded spin (default), 1 = hipStreamWaitValue32,
  *                  2 = the edge tiles / edge chunks of the consuming launch poll the flag words themselves (compact
  *                  launch sets only, elsewhere like 0)
- *   "compact"      peer transport + LDS-tile kernel (small slabs): -1/1 = one launch per launch set on one stream, the
- *                  edge tiles store the halo rows into the neighbours themselves; 0 = edge launch / interior launch /
- *                  push kernel on two streams like the larger slabs
+ *   "compact"      peer transport: -1/1 = one launch per launch set on one stream, its first workgroups — the edge tiles /
+ *                  edge chunks — store the halo rows into the neighbours themselves (LDS-tile kernel, three- / four-step
+ *                  kernels, deep window kernel); 0 = edge launch / interior launch / push kernel on two streams
  * Read-only through lbm_get_option: "nslabs", "fuse_units", "halo_depth", "launch_steps" (most timesteps one launch of
  * the context's main kernel advances).
  */
