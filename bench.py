@@ -268,7 +268,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the nx x ny grid is split over the ranks; weak: every rank gets ny rows")
     ap.add_argument("--accel", type=float, default=0.005)
-    ap.add_argument("--valu-calib", type=int, default=40, help="launches (~1 ms each) of the packed-FMA issue-rate calibration; 0 = skip")
+    ap.add_argument("--valu-calib", type=int, default=40, help="launches (~2 ms each) of the packed-FMA issue-rate calibration; 0 = skip")
     ap.add_argument("--calib-iters", type=int, default=10, help="launches of the 1 GiB copy kernel that measures the roofline denominator")
     ap.add_argument("--fuse", type=int, default=-1, help="timesteps per launch of the register/LDS-window kernels: 0, 1 (= 2), 3, 4, 6..8 (d2q9_deep, at most); -1: library default")
     ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl"],
@@ -329,7 +329,7 @@ def main():
     try:
         copy_gbps = round(lbm_amd.copy_bandwidth_gbps(1 << 30, args.calib_iters), 1)
         # ... and the denominator of the kernels that are bound by instruction issue (d2q9_deep): packed-FMA issue rate,
-        # ~1 ms per launch.  Like the copies, this also loads the chip before the warm-up steps (profiles/r02_cold_start.txt).
+        # ~2 ms per launch.  Like the copies, this also loads the chip before the warm-up steps (profiles/r02_cold_start.txt).
         if args.valu_calib > 0:
             valu_tera = round(lbm_amd.valu_rate_tera(args.valu_calib), 2)
     except lbm_amd.LBMError:

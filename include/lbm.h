@@ -222,7 +222,7 @@ int lbm_copy_bandwidth(size_t bytes, int iters, double *gbps);
 
 /* The other roofline denominator, for the kernels that are bound by instruction issue (d2q9_deep): the rate at which the
  * device issues packed fp32 fused multiply-adds (eight independent chains per thread, eight waves per SIMD), in 1e12
- * lane-instructions per second, over `launches` launches of ~1 ms.  (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3.) */
+ * lane-instructions per second, over `launches` launches of ~2 ms.  (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3.) */
 int lbm_valu_rate(int launches, double *tera_lane_instr_per_s);
 
 /* Release everything.  Replaces the clRelease* block of finalise (d2q9-bgk.c:729-741). */

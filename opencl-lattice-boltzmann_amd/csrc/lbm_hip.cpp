@@ -2300,7 +2300,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
 int lbm_valu_rate(int launches, double *tera_lane_instr_per_s) {
   if (!tera_lane_instr_per_s || launches < 1) return fail(LBM_ERR_ARG, "bad argument");
   // 8 workgroups of 256 threads per CU: eight waves per SIMD, each with eight independent chains
-  const int nb = 256 * 8, iters = 4096;  // 4 x 8 packed FMAs per loop iteration: 131072 per thread and launch (~1 ms)
+  const int nb = 256 * 8, iters = 4096;  // 4 x 8 packed FMAs per loop iteration: 131072 per thread and launch (~1.9 ms)
   float *out = nullptr;
   HIP_TRY(hipMalloc((void **)&out, (size_t)nb * kBlock * sizeof(float)));
   hipEvent_t t0, t1;
