@@ -708,6 +708,13 @@ def test_abi_error_behaviour(lbm):
             sim.set_option("no_such_knob", 1)
         with pytest.raises(lbm.LBMError):
             sim.set_option("variant", 9)
+        # the options of the deep window kernel are range-checked like the others
+        for key, bad in (("fuse", 5), ("fuse", 9), ("twin_steps", 1), ("twin_steps", 9), ("obst_paths", 2), ("edge_aware", 2)):
+            with pytest.raises(lbm.LBMError):
+                sim.set_option(key, bad)
+        for key, good in (("twin_steps", 0), ("twin_steps", 8), ("obst_paths", -1), ("edge_aware", -1), ("fuse", 7), ("fuse", -1)):
+            sim.set_option(key, good)
+        sim.set_option("twin_steps", 0)
         with pytest.raises(lbm.LBMError, match="max_iters"):
             sim.run(5)
         sim.run(4)
