@@ -16,8 +16,12 @@ REF_AV_VELS_FILE=check/128x128.av_vels.dat
 
 all: $(LIB) $(EXE) $(EXE).exe oracle
 
-$(LIB): $(PKG)/csrc/lbm_hip.cpp $(PKG)/csrc/d2q9_kernels.h include/lbm.h
-	$(HIPCC) $(HIPFLAGS) -shared $(PKG)/csrc/lbm_hip.cpp -o $@ -ldl
+# lbm_version() carries a digest of the device + host sources the library was built from: a committed profile
+# (profiles/traffic.json) names the build it measured, and bench.py refuses its counters for any other build
+SRC_ID = $(shell cat $(PKG)/csrc/d2q9_kernels.h $(PKG)/csrc/halo_exchange.h $(PKG)/csrc/lbm_hip.cpp | sha256sum | cut -c1-12)
+
+$(LIB): $(PKG)/csrc/lbm_hip.cpp $(PKG)/csrc/d2q9_kernels.h $(PKG)/csrc/halo_exchange.h include/lbm.h
+	$(HIPCC) $(HIPFLAGS) -DLBM_SRC_ID=\"$(SRC_ID)\" -shared $(PKG)/csrc/lbm_hip.cpp -o $@ -ldl
 
 $(EXE): $(PKG)/host/d2q9-bgk.c include/lbm.h $(LIB)
 	$(CC) -std=c99 -O2 -Wall -D_GNU_SOURCE -Iinclude $(PKG)/host/d2q9-bgk.c -o $@ -L$(PKG) -llbm_hip -lm -lpthread -Wl,-rpath,'$$ORIGIN/$(PKG)'

@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its own ranks: before anything touches the GPU
+it runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (one rank per GPU over
+RCCL), relays rank 0's JSON line and exits with the child's code (--launcher one-process: the lbm_create(ndev=N) form
+of INTEGRATION.md section 3 instead, one process driving N slabs; the line says which).
+
 A "step" is one lattice-Boltzmann timestep (accelerate_flow + stream + collide + av_vels reduction, the reference's
 loop body d2q9-bgk.c:221-238) over the whole grid.  Workload: the synthetic 8192x8192 lid-driven cavity of
 BASELINE.json (only the four border lines blocked), uniform rest initial state, fp32.  With N > 1 the grid is
@@ -80,8 +85,10 @@ def cpu_model():
     return "unknown CPU"
 
 
-def oracle_rate(precision, nx, ny, obstacles, accel, budget_s, max_steps, omp=False):
-    """(steps, seconds) of one oracle build on an nx x ny grid: at least 2 steps, at most max_steps / budget_s"""
+def oracle_rate(precision, nx, ny, obstacles, accel, budget_s, max_steps, omp=False, av_out=None):
+    """(steps, seconds) of one oracle build on an nx x ny grid from the uniform rest state: at least 2 steps, at most
+    max_steps / budget_s.  av_out (a list) receives av_vels[0..] of the steps taken, the untimed first one included —
+    the record bench.py holds the timed GPU context's av_vels against (`result_check`)."""
     from oracle.oracle import Oracle
     orc = Oracle(precision, omp=omp)
     p = orc.make_params(nx, ny, 1, 10, 0.1, accel, 1.85)
@@ -89,27 +96,29 @@ def oracle_rate(precision, nx, ny, obstacles, accel, budget_s, max_steps, omp=Fa
     src = orc.init_cells(p)
     dst = np.empty_like(src)
     orc.accelerate_flow(p, src, obstacles)   # one untimed step for page faults
-    orc.timestep(p, src, dst, obstacles)
+    av = [orc.timestep(p, src, dst, obstacles)]
     src, dst = dst, src
     n, t0 = 0, time.perf_counter()
     while True:
         orc.accelerate_flow(p, src, obstacles)
-        orc.timestep(p, src, dst, obstacles)
+        av.append(orc.timestep(p, src, dst, obstacles))
         src, dst = dst, src
         n += 1
         el = time.perf_counter() - t0
         if n >= 2 and (el > budget_s or n >= max_steps):
             break
+    if av_out is not None:
+        av_out.extend(av)
     return n, el
 
 
-def cpu_baseline(nx, ny, obstacles, accel):
+def cpu_baseline(nx, ny, obstacles, accel, av_out=None):
     """Serial fp32 oracle, 1 thread, on a bounded sample of the headline workload (`value`), plus the other figures
     SURVEY.md 8(d) asks for: the 128x128 input run to the end and sent through the checker (BASELINE config 1), the
     rate on the 1024x1024 input (200 steps) in fp32 and fp64, and an OpenMP figure over this process's CPU share.
     About 35 s of CPU work in all."""
     model, ncpu = cpu_model(), os.cpu_count()
-    n, el = oracle_rate("f32", nx, ny, obstacles, accel, 9.0, 64)
+    n, el = oracle_rate("f32", nx, ny, obstacles, accel, 9.0, 64, av_out=av_out)
     out = {"value": round(nx * ny * n / el / 1e6, 2), "unit": "MLUPS", "cores": 1, "kind": "port",
            "sample": "%d timesteps of the same %dx%d grid with the serial fp32 oracle (oracle/d2q9_oracle.c, gcc -O3 "
                      "-march=native, 1 of %d host cores, %s)" % (n, nx, ny, ncpu, model)}
@@ -203,58 +212,309 @@ def min_over_ranks(dist, value, device):
     return float(t[0])
 
 
+class TransportFailed(RuntimeError):
+    """raised on EVERY rank alike (the ranks vote) when a halo transport failed on any of them"""
+
+
+class Env:
+    """what every leg needs: the library binding, torch.distributed and this rank's place in the job"""
+
+    def __init__(self, lbm_amd, torch, dist, rank, world, local_rank, device):
+        self.lbm, self.torch, self.dist = lbm_amd, torch, dist
+        self.rank, self.world, self.local_rank, self.device = rank, world, local_rank, device
+
+    def all_ok(self, ok):
+        """the ranks' vote: True only if every rank says so (an all-reduce, so it also lines the ranks up)"""
+        return min_over_ranks(self.dist, 1.0 if ok else 0.0, self.device) > 0.5
+
+
+PEER_TIMEOUT_MS = 5000   # bench runs: a rank waits this long for a neighbour's halo rows (library default: 30 s)
+
+
 class RankSim:
-    """One rank's slab of a row-partitioned grid and the halo transports it can use."""
+    """One rank's slab of a row-partitioned grid on ONE halo transport ("rccl": grouped send/recv; "peer": stores into
+    the neighbours' HIP-IPC-mapped grids).  Every rank takes part in every collective in here whatever happened to
+    it — a failed descriptor travels as a zero blob, a failed mapping as a 'no' vote — so that no rank is left
+    blocked in a collective the others skipped."""
 
-    def __init__(self, lbm_amd, dist, rank, world, local_rank, params, obstacles, want, device):
-        cid = share_comm_id(dist, rank, lbm_amd.comm_id() if rank == 0 else None, lbm_amd.load_library().lbm_comm_id_size(), device)
-        self.sim = lbm_amd.LBM(params, obstacles, rank=rank, nranks=world, device=local_rank, comm=cid)
-        self.transports = ["rccl"]
-        self.peer_error = None
-        if want in ("peer", "both"):
-            # every rank maps its ring neighbours' grids through HIP IPC; the ring uses them only if ALL ranks could
-            ok = 1.0
+    def __init__(self, env, params, obstacles, transport):
+        lbm_amd, dist = env.lbm, env.dist
+        cid = share_comm_id(dist, env.rank, lbm_amd.comm_id() if env.rank == 0 else None,
+                            lbm_amd.load_library().lbm_comm_id_size(), env.device)
+        self.sim = lbm_amd.LBM(params, obstacles, rank=env.rank, nranks=env.world, device=env.local_rank, comm=cid)
+        self.transport = transport
+        self.error = None
+        if transport == "peer":
+            size = lbm_amd.load_library().lbm_peer_info_size()
             try:
-                infos = gather_blobs(dist, self.sim.peer_info(), world, device)
-                self.sim.connect_peers(infos[(rank - 1) % world], infos[(rank + 1) % world])
+                blob = self.sim.peer_info()
             except lbm_amd.LBMError as e:
-                ok, self.peer_error = 0.0, str(e)
-            if min_over_ranks(dist, ok, device) > 0.5:
-                self.transports = ["peer"] if want == "peer" else ["peer", "rccl"]
-            elif self.sim.get_option("transport") == 3:
-                self.sim.set_option("transport", 1)
+                blob, self.error = bytes(size), str(e)
+            infos = gather_blobs(dist, blob, env.world, env.device)
+            if all(any(b) for b in infos):          # the same answer on every rank
+                try:
+                    self.sim.connect_peers(infos[(env.rank - 1) % env.world], infos[(env.rank + 1) % env.world])
+                    self.sim.set_option("transport", 3)   # (a context with a communicator stays on RCCL until told)
+                    self.sim.set_option("halo_timeout_ms", PEER_TIMEOUT_MS)
+                except lbm_amd.LBMError as e:
+                    self.error = str(e)
+            elif not self.error:
+                self.error = "a rank of the ring has no peer descriptor"
+            if not env.all_ok(self.error is None):
+                self.error = self.error or "another rank could not map its ring neighbours"
+                self.close()
+                raise TransportFailed("peer: " + self.error)
 
-    def use(self, name):
-        self.sim.set_option("transport", {"rccl": 1, "peer": 3}[name])
+    def close(self):
+        if self.sim is not None:
+            self.sim.close()
+            self.sim = None
 
 
-def timed_run(sim, dist, device, torch, warmup, steps):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
-    def fence():
+def synced(env, sim):
+    """lbm_sync on every rank, then the vote: a transport that failed on one rank (LBM_ERR_COMM: a neighbour's halo
+    rows never came, an RCCL error) is a failure on all of them — nobody walks into the next collective alone"""
+    err = None
+    try:
         sim.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        env.torch.cuda.synchronize()
+    except env.lbm.LBMError as e:
+        err = str(e)
+    if env.dist is None:
+        if err:
+            raise TransportFailed(err)
+        return
+    if not env.all_ok(err is None):
+        raise TransportFailed(err or "another rank's halo transport failed")
+
+
+def timed_run(env, sim, warmup, steps):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
     sim.run(warmup)
-    fence()
+    synced(env, sim)           # sync + all-reduce vote = the barrier of the contract
     t0 = time.perf_counter()
     loop_ms = sim.run_timed(steps)   # HIP events on the stream the step kernels run on
-    fence()
+    synced(env, sim)
     wall = time.perf_counter() - t0
-    if dist is not None:
-        wall, loop_ms = max_over_ranks(dist, [wall, loop_ms], device)
+    if env.dist is not None:
+        wall, loop_ms = max_over_ranks(env.dist, [wall, loop_ms], env.device)
     return wall, loop_ms
 
 
-def profile_all_ranks(sim, dist, rank, world, device, nsteps, extra):
+def profile_all_ranks(env, sim, nsteps, extra):
     """lbm_run_profiled on every rank, gathered on all: where a launch set's time goes (edge / exchange / interior)"""
     st = sim.run_profiled(nsteps)
     st = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()}
-    st.update(rank=rank, **extra)
-    if st.get("peer_error"):
-        st["peer_error"] = st["peer_error"][:160]
+    st.update(rank=env.rank, **extra)
     blob = json.dumps(st).encode().ljust(1024)[:1024]
-    return [json.loads(b.decode().strip()) for b in gather_blobs(dist, blob, world, device)]
+    return [json.loads(b.decode().strip()) for b in gather_blobs(env.dist, blob, env.world, env.device)]
+
+
+def rank_leg(env, params, obstacles, transports, warmup, steps, fuse=-1, profile=True, want_av=False):
+    """One workload over the ranks, once per halo transport — a fresh context each, so that a transport that fails
+    leaves nothing behind for the next.  Returns {transport: {...}}; a failed transport has an "error" instead of times."""
+    runs = {}
+    for tr in transports:
+        entry, rs = {}, None
+        try:
+            rs = RankSim(env, params, obstacles, tr)
+            sim = rs.sim
+            if fuse >= 0:
+                sim.set_option("fuse", fuse)
+            sim.upload(None)  # uniform rest state, built on the device
+            entry["wall_s"], entry["loop_ms"] = timed_run(env, sim, warmup, steps)
+            entry["row_range"] = sim.row_range()
+            entry["options"] = {k: sim.get_option(k) for k in ("fuse", "pair", "launch_steps", "multistep", "halo_depth")}
+            if want_av:
+                entry["av"] = sim.download(cells=False)[1]     # collective (RCCL all-reduce): every rank got here
+            if profile:
+                per = max(entry["options"]["multistep"], entry["options"]["launch_steps"], 1)
+                entry["per_rank"] = profile_all_ranks(env, sim, 8 * per, dict(rows=entry["row_range"][1] - entry["row_range"][0]))
+                synced(env, sim)
+        except TransportFailed as e:
+            entry = {"error": str(e)[:300]}
+        finally:
+            if rs is not None:
+                rs.close()
+        runs[tr] = entry
+    return runs
+
+
+def max_rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)))
+
+
+def transport_check(env, transports, nsteps=64):
+    """Every halo transport against the ORACLE before any of them is timed or chosen: the reference's 1024x1024
+    obstacles row-partitioned over the ranks (128 rows each at 8 GPUs), a seeded random non-equilibrium state — every
+    slab boundary carries non-trivial data from the first step on, unlike a cavity at rest — 64 timesteps (8 exchanges
+    of 8 halo rows).  Each rank compares its own rows of every distribution (<= 2e-5 relative) and the all-reduced
+    av_vels record (<= 1e-4) with the fp32 oracle's (oracle/d2q9_oracle.c restating kernels.cl:9-231), computed on this
+    rank's host cores.  A transport that delivers stale, misplaced or late halo rows over xGMI fails here and is
+    neither timed nor reported as `value`."""
+    from oracle.oracle import Oracle
+    lbm_amd = env.lbm
+    p2, ob2 = shipped("1024x1024")
+    p2.max_iters = nsteps + 8
+    rng = np.random.default_rng(2026)
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
+    cells0 = (w * (1.0 + 0.2 * (rng.random((9, 1024, 1024)) - 0.5))).astype(np.float32)
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(8, len(os.sched_getaffinity(0)) // max(1, env.world))))
+    orc = Oracle("f32", omp=True)
+    po = orc.make_params(1024, 1024, nsteps, p2.reynolds_dim, p2.density, p2.accel, p2.omega)
+    orc.set_obstacles(po, ob2)
+    ref = cells0.copy()
+    av_ref = orc.run(po, ref, ob2, nsteps)
+    out = {}
+    for tr in transports:
+        res, rs = {}, None
+        try:
+            rs = RankSim(env, p2, ob2, tr)
+            rs.sim.upload(cells0)
+            rs.sim.run(nsteps)
+            synced(env, rs.sim)
+            got, av = rs.sim.download()
+            y0, y1 = rs.sim.row_range()
+            ec, ea = max_rel(got[:, y0:y1], ref[:, y0:y1]), max_rel(av, av_ref)
+            ec, ea = max_over_ranks(env.dist, [ec, ea], env.device)
+            res = {"ok": bool(ec < 2e-5 and ea < 1e-4), "cells_max_rel": float("%.3g" % ec), "av_vels_max_rel": float("%.3g" % ea),
+                   "halo_depth": rs.sim.get_option("halo_depth")}
+        except TransportFailed as e:
+            res = {"ok": False, "error": str(e)[:300]}
+        finally:
+            if rs is not None:
+                rs.close()
+        out[tr] = res
+    return {"workload": "input_1024x1024 obstacles, seeded random state, %d timesteps, rows x%d, vs the fp32 oracle "
+                        "(cells <= 2e-5, av_vels <= 1e-4 relative)" % (nsteps, env.world), "transports": out}
+
+
+def result_check(av_gpu, av_oracle, tol=1e-4):
+    """`result_ok`: the timed context's av_vels[0..n) against the oracle's for the same steps from the same rest state
+    on the same grid (kernels.cl:198 — every cell's |u| enters every step's entry: a launch that skipped levels, rows
+    or strips shows here)"""
+    n = min(len(av_gpu), len(av_oracle))
+    if n < 2 or not np.all(np.isfinite(av_gpu)) or not av_gpu[-1] > 0:
+        return False, {"compared_steps": n, "error": "no finite positive av_vels record to compare"}
+    dev = max_rel(av_gpu[:n], av_oracle[:n])
+    return bool(dev < tol), {"compared_steps": n, "av_vels_max_rel_vs_oracle": float("%.3g" % dev), "tolerance": tol,
+                             "what": "av_vels[0..%d) of the timed context vs the fp32 oracle stepped from the same rest state" % n}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the ranks as a child process.  This process never
+    imports the HIP library and never touches the GPU (a process that has may not be replaced or forked safely on this
+    pool); it relays rank 0's JSON line and the exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, LBM_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, 9)     # exactly the process group started above
+        out, _ = proc.communicate()
+        sys.stdout.write(out or "")
+        raise SystemExit("bench.py --gpus %d: the ranks did not finish within %d s" % (args.gpus, args.launch_timeout))
+    lines = (out or "").splitlines()
+    for ln in lines:
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    js = [ln for ln in lines if ln.startswith('{"metric"')]
+    if js:
+        print(js[-1], flush=True)
+    if proc.returncode != 0:
+        raise SystemExit("bench.py --gpus %d: the ranks started with torch.distributed.run exited with code %d (their messages are above)"
+                         % (args.gpus, proc.returncode))
+    if not js:
+        raise SystemExit("bench.py --gpus %d: rank 0 printed no result line" % args.gpus)
+
+
+def roofline_of(nx, rows_local, steps, loop_ms, multistep, fused, deep, twin):
+    """the roofline object of the module docstring for the dominant kernel of one leg"""
+    steps_per_launch = multistep if multistep else (fused if fused else 1)
+    launches = steps // steps_per_launch + steps % steps_per_launch
+    if deep and not multistep and steps >= 2:
+        # d2q9_deep: the run is split into the fewest launches, of equal depth (20 steps = 7+7+6)
+        launches = -(-steps // fused)
+        steps_per_launch = steps / launches
+    launch_s = loop_ms * 1e-3 / launches
+    cells_local = nx * rows_local
+    model_bytes = (BYTES_PER_LU + MASK_BYTES) * cells_local
+    achieved = model_bytes / launch_s / 1e9
+    alg_gbps = BYTES_PER_LU * cells_local * steps_per_launch / launch_s / 1e9
+    return {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "kernel": ("d2q9_multi (%d timesteps per launch on LDS tiles)" % multistep) if multistep else (
+            "d2q9_deep%s (up to %d timesteps per launch, lanes of two cells)" % ("_twin" if twin else "", fused) if deep else KERNELS[fused]),
+        "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": round(steps_per_launch, 3),
+        "model_bytes_per_launch": model_bytes,
+        "formula": "achieved = model_bytes_per_launch / launch_us; model_bytes_per_launch = (72 + 1) B x %d cells of the "
+                   "rank's slab: a launch reads the grid once, writes it once and reads the byte mask, however many "
+                   "timesteps it advances; launch_us = HIP-event time of the step loop / launches" % cells_local,
+        "algorithmic": {"bytes_per_lattice_update": BYTES_PER_LU, "gbps": round(alg_gbps, 1),
+                        "frac_of_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
+                        "formula": "72 B x cells x steps_per_launch / launch_us (SURVEY.md 8d); above the 8 TB/s peak where "
+                                   "temporal blocking keeps steps_per_launch-1 intermediate states on the chip: the "
+                                   "speed-up over a perfect one-step-per-launch kernel, not a bandwidth"}}
+
+
+def kernel_shape(opts):
+    """(fused, deep, twin, multistep) from a context's read-back options"""
+    fused = {0: 0, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[opts["fuse"]]   # timesteps per launch of the dominant kernel (0: one)
+    deep = fused >= 6
+    twin = bool(deep and opts["pair"])   # d2q9_deep_twin (chunk pairs, at most five steps per launch)
+    if deep:
+        fused = opts["launch_steps"]
+    return fused, deep, twin, opts["multistep"]
+
+
+def attach_traffic(rf, lups, nx, ny, deep, twin, steps_per_launch, model_bytes, launch_s, valu_tera, version):
+    """measured PMC traffic of the same command, when a profile of this workload AND of this build is committed"""
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tp):
+        return
+    with open(tp) as f:
+        tj = json.load(f)
+    key = "%dx%d/%s" % (nx, ny, ("deep_twin" if twin else "deep") if deep else "step%d" % steps_per_launch)
+    if key not in tj:
+        return
+    ent = tj[key]
+    if ent.get("library_version") != version:
+        # counters of another build say nothing about this one: refuse them rather than let them go stale silently
+        rf["traffic_refused"] = {"reason": "profiles/traffic.json[%s] was measured on library '%s', this is '%s'"
+                                           % (key, ent.get("library_version"), version), "source": ent.get("source")}
+        return
+    tb = ent["hbm_bytes_per_launch"]
+    rf["traffic"] = tb
+    rf["traffic_measured_in_run"] = False
+    rf["traffic_source"] = ent.get("source")
+    rf["traffic_frac"] = round(tb / launch_s / 1e9 / HBM_PEAK_GBPS, 4)
+    rf["traffic_over_model"] = round(tb / model_bytes, 4)
+    if ent.get("evidence"):
+        rf["bound_evidence"] = ent["evidence"]
+        # `bound` names the roofline `frac` is priced against (the metric's: HBM); which resource the
+        # kernel actually runs out of first is read off the counters of the committed profile
+        vs = ent["evidence"].get("valu_issue_share")
+        if vs is not None:
+            rf["limited_by"] = "valu_issue" if vs > rf["traffic_frac"] else "hbm"
+    if valu_tera:
+        # issue-rate roofline: VALU lane-instructions the kernel executes per lattice update (committed profile) x rate
+        lane = (rf.get("bound_evidence") or {}).get("valu_lane_instr_per_cell_step")
+        rf["valu"] = {"issue_rate_measured": valu_tera, "unit": "1e12 packed-fp32 lane-instructions/s", "theoretical": 39.3,
+                      "lane_instr_per_cell_step": lane, "lane_instr_source": "SQ_INSTS_VALU of the committed profile" if lane else None,
+                      "achieved": round(lane * lups / 1e12, 2) if lane else None,
+                      "frac": round(lane * lups / 1e12 / valu_tera, 4) if lane else None}
 
 
 def main():
@@ -266,16 +526,32 @@ def main():
     ap.add_argument("--ny", type=int, default=8192)
     ap.add_argument("--workload", default="cavity", choices=["cavity", "empty", "tiled"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="strong: the nx x ny grid is split over the ranks; weak: every rank gets ny rows")
+                    help="what `value` is: strong = the nx x ny grid split over the ranks (default; the weak-scaling figure is "
+                         "then the `weak` object of the same line), weak = every rank gets ny rows")
     ap.add_argument("--accel", type=float, default=0.005)
     ap.add_argument("--valu-calib", type=int, default=40, help="launches (~2 ms each) of the packed-FMA issue-rate calibration; 0 = skip")
     ap.add_argument("--calib-iters", type=int, default=10, help="launches of the 1 GiB copy kernel that measures the roofline denominator")
     ap.add_argument("--fuse", type=int, default=-1, help="timesteps per launch of the register/LDS-window kernels: 0, 1 (= 2), 3, 4, 6..8 (d2q9_deep, at most); -1: library default")
     ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl"],
-                    help="N > 1: halo transport(s) to measure; the faster one is `value`")
+                    help="N > 1: halo transport(s) to check against the oracle and measure; the faster one that passed is `value`")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "torchrun", "one-process"],
+                    help="--gpus N without WORLD_SIZE in the environment: auto/torchrun = start `python -m torch.distributed.run` "
+                         "with N ranks as a child process (torchrun also for N = 1: the rank path on one GPU); one-process = "
+                         "one process drives N slabs (lbm_create(ndev=N))")
+    ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the self-launched ranks get")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 1024x1024 and reference-rule side measurements")
+    ap.add_argument("--no-cold", action="store_true", help="skip `value_cold` (the same steps before any calibration launch)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 1024x1024, weak-scaling and reference-rule side measurements")
     args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ
+    one_process = False
+    if not launched and (args.gpus > 1 or args.launcher == "torchrun"):
+        import importlib.util
+        have = importlib.util.find_spec("torch") is not None and importlib.util.find_spec("torch.distributed.run") is not None
+        if args.launcher != "one-process" and have:
+            return self_launch(args, sys.argv[1:])
+        one_process = True   # no launcher on this machine (or asked for): INTEGRATION.md section 3's one-process form
 
     import torch  # device plumbing + torch.distributed (RCCL) only
     import lbm_amd
@@ -283,212 +559,182 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed launch with that many ranks" % args.gpus)
+    if launched and world != args.gpus:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # one GPU per rank; if the launcher narrowed the visible devices per rank, index within what is visible
-    local_rank = local_rank % torch.cuda.device_count()
+    visible = torch.cuda.device_count()
+    if max(world, args.gpus) > visible:
+        if rank == 0:
+            print("bench.py: %d GPUs needed, %d visible" % (max(world, args.gpus), visible), file=sys.stderr, flush=True)
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    # LBM_BENCH_RANK_MODE=1 drives the one-process-per-GPU code path with a single rank: the rank is its own ring
-    # neighbour (default "force_halo"), so torch.distributed + the library's RCCL communicator run on a one-GPU box
-    rank_mode = world > 1 or os.environ.get("LBM_BENCH_RANK_MODE") == "1"
+    # A single rank started by the launcher (LBM_BENCH_CHILD, or LBM_BENCH_RANK_MODE=1 by hand) drives the
+    # one-process-per-GPU code path as a ring of one: the rank is its own ring neighbour (default "force_halo"), so
+    # torch.distributed + the library's RCCL communicator + both transports run on a one-GPU box
+    rank_mode = world > 1 or os.environ.get("LBM_BENCH_RANK_MODE") == "1" or (launched and os.environ.get("LBM_BENCH_CHILD") == "1")
     if rank_mode and world == 1:
         lbm_amd.set_default("force_halo", 1)
     dist = init_dist("nccl", rank, world, device) if rank_mode else None
+    env = Env(lbm_amd, torch, dist, rank, world, local_rank, device)
+    version = lbm_amd.load_library().lbm_version().decode()
 
     nx = args.nx
     ny = args.ny * (world if args.scaling == "weak" else 1)
-    total_steps = (2 if rank_mode else 1) * (args.warmup + args.steps) + 256
+    total_steps = args.warmup + args.steps + 256
     obstacles = make_workload(args.workload, nx, ny)
     params = lbm_amd.make_params(nx, ny, total_steps, 10, 0.1, args.accel, 1.85, obstacles)
+    ndev = args.gpus if one_process else 1
 
-    rs = None
-    if rank_mode:
-        rs = RankSim(lbm_amd, dist, rank, world, local_rank, params, obstacles, args.transport, device)
-        sim, transports = rs.sim, rs.transports
-    else:
-        sim, transports = lbm_amd.LBM(params, obstacles), [None]
-    if args.fuse >= 0:
-        sim.set_option("fuse", args.fuse)
-    fused = {0: 0, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[sim.get_option("fuse")]   # timesteps per launch of the dominant kernel (0: one)
-    deep = fused >= 6
-    twin = bool(deep and sim.get_option("pair"))   # d2q9_deep_twin (chunk pairs, at most five steps per launch)
-    if deep:
-        fused = sim.get_option("launch_steps")
-    multistep = sim.get_option("multistep")
-    sim.upload(None)  # uniform rest state, built on the device
-    y0, y1 = sim.row_range()
+    def plain_leg(p, ob, warmup, steps, fuse=-1, want_av=False):
+        """one context in this process (one slab, or --launcher one-process: one slab per device)"""
+        with (lbm_amd.LBM(p, ob, devices=list(range(ndev))) if ndev > 1 else lbm_amd.LBM(p, ob)) as sim:
+            if fuse >= 0:
+                sim.set_option("fuse", fuse)
+            sim.upload(None)
+            e = {}
+            e["wall_s"], e["loop_ms"] = timed_run(env, sim, warmup, steps)
+            e["row_range"] = sim.row_range()
+            e["options"] = {k: sim.get_option(k) for k in ("fuse", "pair", "launch_steps", "multistep", "halo_depth")}
+            if want_av:
+                e["av"] = sim.download(cells=False)[1]
+            if ndev > 1:
+                per = max(e["options"]["multistep"], e["options"]["launch_steps"], 1)
+                st = sim.run_profiled(8 * per)
+                e["per_rank"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()}]
+            return e
 
-    # the roofline denominator first (a float4 copy of 1 GiB each way, ~10 launches): measured anyway, and done here it
-    # also brings the chip to its working clock before the W warm-up steps (the driver's W = 5 is one launch)
+    # ---- `value_cold`: the same W + K steps BEFORE anything else has run on the chip (no copy calibration, no issue-rate
+    # calibration): the first ~40 ms of the VALU-bound default kernel run 8-10 % below its steady state on a chip that has
+    # not been loaded yet (profiles/r02_cold_start.txt), and a 20-step record is mostly those milliseconds
+    cold = None
+    if not args.no_cold:
+        if rank_mode:
+            c = rank_leg(env, params, obstacles, ["rccl"], args.warmup, args.steps, args.fuse, profile=False)["rccl"]
+        else:
+            c = plain_leg(params, obstacles, args.warmup, args.steps, args.fuse)
+        if "wall_s" in c:
+            cold = round(nx * ny * args.steps / c["wall_s"] / 1e6, 1)
+
+    # ---- the two roofline denominators (a float4 copy of 1 GiB each way; packed-FMA issue rate, ~1.9 ms per launch):
+    # measured anyway, and done here they also bring the chip to its working clock before the W warm-up steps
     copy_gbps = valu_tera = None
+    pre = {"copy_launches": 0, "copy_ms": 0.0, "valu_calib_launches": 0, "valu_calib_ms": 0.0,
+           "what": "calibration launches that run between context creation and the W warm-up steps; `value_cold` is the "
+                   "same W + K steps measured before any of them, in a context of its own"}
     try:
+        t0 = time.perf_counter()
         copy_gbps = round(lbm_amd.copy_bandwidth_gbps(1 << 30, args.calib_iters), 1)
-        # ... and the denominator of the kernels that are bound by instruction issue (d2q9_deep): packed-FMA issue rate,
-        # ~2 ms per launch.  Like the copies, this also loads the chip before the warm-up steps (profiles/r02_cold_start.txt).
+        pre["copy_launches"], pre["copy_ms"] = args.calib_iters, round((time.perf_counter() - t0) * 1e3, 1)
         if args.valu_calib > 0:
+            t0 = time.perf_counter()
             valu_tera = round(lbm_amd.valu_rate_tera(args.valu_calib), 2)
+            pre["valu_calib_launches"], pre["valu_calib_ms"] = args.valu_calib, round((time.perf_counter() - t0) * 1e3, 1)
     except lbm_amd.LBMError:
         pass
 
-    # ---- the timed region(s): one per halo transport, the faster one is reported as `value` -----------------------
-    runs = {}
-    for tr in transports:
-        if tr:
-            rs.use(tr)
-        wall, loop_ms = timed_run(sim, dist, device, torch, args.warmup, args.steps)
-        runs[tr or "single"] = {"wall_s": wall, "loop_ms": loop_ms}
-    best = min(runs, key=lambda k: runs[k]["wall_s"])
-    wall, loop_ms = runs[best]["wall_s"], runs[best]["loop_ms"]
-    # where a launch set's time goes on every rank (timing events; a separate short run, outside the timed region)
-    per_rank = None
+    # ---- N ranks: every transport against the oracle first; only those that pass are timed ---------------------------
+    tcheck, transports = None, [None]
     if rank_mode:
-        rs.use(best)
-        per_rank = profile_all_ranks(sim, dist, rank, world, device, 8 * max(multistep, fused, 1),
-                                     dict(rows=y1 - y0, rccl_world=world, transports_available=transports, peer_error=rs.peer_error))
+        want = {"both": ["rccl", "peer"], "peer": ["peer"], "rccl": ["rccl"]}[args.transport]
+        tcheck = transport_check(env, want)
+        transports = [t for t in want if tcheck["transports"][t]["ok"]]
 
-    # sanity on the result of the timed run: finite, positive average velocity on every rank
-    _, av = sim.download(cells=False)
-    ok = bool(np.all(np.isfinite(av)) and av[-1] > 0)
+    # ---- the timed region(s): one per halo transport, the faster one is reported as `value` -----------------------
+    if rank_mode:
+        runs = rank_leg(env, params, obstacles, transports, args.warmup, args.steps, args.fuse, want_av=True)
+    else:
+        runs = {"single" if ndev == 1 else "one-process": plain_leg(params, obstacles, args.warmup, args.steps, args.fuse, want_av=True)}
+    good = {k: v for k, v in runs.items() if "wall_s" in v}
 
-    out = None
-    if rank == 0:
+    out, ok = None, False
+    av_oracle = []
+    if rank == 0 and not good:
+        out = {"metric": "MLUPS", "value": None, "unit": "MLUPS (million lattice updates/s)", "n_gpus": max(world, ndev),
+               "steps": args.steps, "warmup": args.warmup, "result_ok": False, "transport_check": tcheck,
+               "transports": {k: v for k, v in runs.items()},
+               "error": "no halo transport passed the oracle check and completed the timed run"}
+    if rank == 0 and good:
+        best = min(good, key=lambda k: good[k]["wall_s"])
+        b = good[best]
+        wall, loop_ms = b["wall_s"], b["loop_ms"]
+        y0, y1 = b["row_range"]
+        fused, deep, twin, multistep = kernel_shape(b["options"])
         lups = nx * ny * args.steps / wall
-        rows_local = y1 - y0
-        # the dominant kernel advances `steps_per_launch` timesteps of the rank's slab per launch
-        steps_per_launch = multistep if multistep else (fused if fused else 1)
-        launches = args.steps // steps_per_launch + args.steps % steps_per_launch
-        if deep and not multistep and args.steps >= 2:
-            # d2q9_deep: the run is split into the fewest launches, of equal depth (20 steps = 7+7+6)
-            launches = -(-args.steps // fused)
-            steps_per_launch = args.steps / launches
-        launch_s = loop_ms * 1e-3 / launches
-        cells_local = nx * rows_local
-        model_bytes = (BYTES_PER_LU + MASK_BYTES) * cells_local
-        achieved = model_bytes / launch_s / 1e9
-        alg_gbps = BYTES_PER_LU * cells_local * steps_per_launch / launch_s / 1e9
+        rows_local = (y1 - y0) if ndev == 1 else ny // ndev
+        rf = roofline_of(nx, rows_local, args.steps, loop_ms, multistep, fused, deep, twin)
         out = {
             "metric": "MLUPS", "value": round(lups / 1e6, 1), "unit": "MLUPS (million lattice updates/s)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": max(world, ndev), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall * 1e3 / args.steps, 5), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d %s, D2Q9-BGK fused timestep, uniform rest start" % (nx, ny, {
                 "cavity": "lid-driven cavity (4 border lines blocked)", "empty": "no obstacles (periodic)",
                 "tiled": "obstacles_1024x1024 tiled up"}[args.workload]),
-                "nx": nx, "ny": ny, "rows_per_gpu": rows_local, "partition": "rows x%d" % world,
+                "nx": nx, "ny": ny, "rows_per_gpu": rows_local, "partition": "rows x%d" % max(world, ndev),
                 "omega": 1.85, "accel": args.accel, "density": 0.1},
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": ("d2q9_multi (%d timesteps per launch on LDS tiles)" % multistep) if multistep else (
-                    "d2q9_deep%s (up to %d timesteps per launch, lanes of two cells)" % ("_twin" if twin else "", fused) if deep else KERNELS[fused]),
-                "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": round(steps_per_launch, 3),
-                "model_bytes_per_launch": model_bytes,
-                "formula": "achieved = model_bytes_per_launch / launch_us; model_bytes_per_launch = (72 + 1) B x %d cells of the "
-                           "rank's slab: a launch reads the grid once, writes it once and reads the byte mask, however many "
-                           "timesteps it advances; launch_us = HIP-event time of the step loop / launches" % cells_local,
-                "algorithmic": {"bytes_per_lattice_update": BYTES_PER_LU, "gbps": round(alg_gbps, 1),
-                                "frac_of_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
-                                "formula": "72 B x cells x steps_per_launch / launch_us (SURVEY.md 8d); above the 8 TB/s peak where "
-                                           "temporal blocking keeps steps_per_launch-1 intermediate states on the chip: the "
-                                           "speed-up over a perfect one-step-per-launch kernel, not a bandwidth"}},
-            "result_ok": ok,
+            "roofline": rf, "library": version,
+            "launcher": ("torch.distributed.run started by bench.py itself" if os.environ.get("LBM_BENCH_CHILD") == "1" else
+                         "external (WORLD_SIZE in the environment)") if launched else
+                        ("one process, lbm_create(ndev=%d)" % ndev if ndev > 1 else "none (single GPU)"),
+            "value_cold": cold, "pre_warmup": pre,
         }
-        # measured PMC traffic of the same command, when a profile of this workload is committed
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1 and not multistep:
-            with open(tp) as f:
-                tj = json.load(f)
-            key = "%dx%d/%s" % (nx, ny, ("deep_twin" if twin else "deep") if deep else "step%d" % steps_per_launch)
-            if key in tj:
-                tb = tj[key]["hbm_bytes_per_launch"]
-                rf = out["roofline"]
-                rf["traffic"] = tb
-                rf["traffic_measured_in_run"] = False
-                rf["traffic_source"] = tj[key].get("source")
-                rf["traffic_frac"] = round(tb / launch_s / 1e9 / HBM_PEAK_GBPS, 4)
-                rf["traffic_over_model"] = round(tb / model_bytes, 4)
-                if tj[key].get("evidence"):
-                    rf["bound_evidence"] = tj[key]["evidence"]
-                    # `bound` names the roofline `frac` is priced against (the metric's: HBM); which resource the
-                    # kernel actually runs out of first is read off the counters of the committed profile
-                    vs = tj[key]["evidence"].get("valu_issue_share")
-                    if vs is not None:
-                        rf["limited_by"] = "valu_issue" if vs > rf["traffic_frac"] else "hbm"
+        if world == 1 and ndev == 1 and not multistep:
+            attach_traffic(rf, lups, nx, ny, deep, twin, int(round(rf["steps_per_launch"])) if not deep else 0,
+                           rf["model_bytes_per_launch"], rf["launch_us"] * 1e-6, valu_tera, version)
+        if valu_tera and "valu" not in rf:
+            rf["valu"] = {"issue_rate_measured": valu_tera, "unit": "1e12 packed-fp32 lane-instructions/s", "theoretical": 39.3,
+                          "lane_instr_per_cell_step": None, "achieved": None, "frac": None}
         # what a plain float4 copy achieves on this box right now (context for `frac`; the spec peak stays `peak`)
-        if valu_tera:
-            # issue-rate roofline: VALU lane-instructions the kernel executes per lattice update (committed profile) x rate
-            lane = (out["roofline"].get("bound_evidence") or {}).get("valu_lane_instr_per_cell_step")
-            out["roofline"]["valu"] = {"issue_rate_measured": valu_tera, "unit": "1e12 packed-fp32 lane-instructions/s",
-                                       "theoretical": 39.3,
-                                       "lane_instr_per_cell_step": lane, "lane_instr_source": "SQ_INSTS_VALU of the committed profile" if lane else None,
-                                       "achieved": round(lane * lups / 1e12, 2) if lane else None,
-                                       "frac": round(lane * lups / 1e12 / valu_tera, 4) if lane else None}
         if copy_gbps:
-            out["roofline"]["copy_kernel_gbps"] = copy_gbps
-            out["roofline"]["frac_of_copy_kernel"] = round(achieved / copy_gbps, 4)
+            rf["copy_kernel_gbps"] = copy_gbps
+            rf["frac_of_copy_kernel"] = round(rf["achieved"] / copy_gbps, 4)
         if rank_mode:
-            out["transports"] = {k: {"value": round(nx * ny * args.steps / v["wall_s"] / 1e6, 1),
-                                     "ms_per_step": round(v["wall_s"] * 1e3 / args.steps, 5)} for k, v in runs.items()}
+            out["transports"] = {k: ({"value": round(nx * ny * args.steps / v["wall_s"] / 1e6, 1),
+                                      "ms_per_step": round(v["wall_s"] * 1e3 / args.steps, 5)} if "wall_s" in v else v)
+                                 for k, v in runs.items()}
             out["transport"] = best
+            out["transport_check"] = tcheck
             out["rccl_world_size"] = world
-            out["per_rank_launch_set_us"] = per_rank
-    sim.close()
+        if b.get("per_rank"):
+            out["per_rank_launch_set_us"] = b["per_rank"]
 
     extra = not args.no_extra and (nx, ny) != (1024, 1024)
-    if extra and rank_mode:
-        # the 1024x1024 input of the reference row-partitioned over the same ranks (BASELINE config 4: strong scaling)
+    if extra and rank_mode and transports:
+        # ---- the 1024x1024 input of the reference row-partitioned over the same ranks (BASELINE config 4: strong scaling)
         p2, ob2 = shipped("1024x1024")
         n2, w2 = 4000, 400
-        p2.max_iters = 2 * (n2 + w2) + 256   # (upload resets the step counter: the cross-check's 600 steps do not count)
-        rs2 = RankSim(lbm_amd, dist, rank, world, local_rank, p2, ob2, args.transport, device)
-        # cross-check of the transports on this grid (128 rows per rank at 8 GPUs: the flow crosses several slab boundaries
-        # within 600 steps): the same 600 steps from rest with every transport must give the same av_vels record up to the
-        # summation order — a transport that delivered stale or misplaced halo rows would not
-        check, records = "ok", {}
-        if len(rs2.transports) > 1:
-            for tr in rs2.transports:
-                rs2.use(tr)
-                rs2.sim.upload(None)
-                rs2.sim.run(600)
-                records[tr] = rs2.sim.download(cells=False)[1].astype(np.float64)
-            ref_tr = "rccl" if "rccl" in records else rs2.transports[0]
-            for tr, av in records.items():
-                dev = float(np.max(np.abs(av - records[ref_tr]) / np.maximum(np.abs(records[ref_tr]), 1e-30)))
-                if not (dev < 1e-5):
-                    check = "FAILED: %s deviates from %s by %.2e" % (tr, ref_tr, dev)
-            if check != "ok":   # every rank holds the same all-reduced records and takes the same decision
-                rs2.transports = [ref_tr]
-        rs2.sim.upload(None)
-        res2 = {}
-        for tr in rs2.transports:
-            rs2.use(tr)
-            res2[tr], _ = timed_run(rs2.sim, dist, device, torch, w2, n2)
-        b2 = min(res2, key=res2.get)
-        rs2.use(b2)
-        pr2 = profile_all_ranks(rs2.sim, dist, rank, world, device, 8 * max(rs2.sim.get_option("multistep"), 3), {})
-        if rank == 0 and check != "ok" and best != rs2.transports[0] and rs2.transports[0] in runs:
-            # the headline run used a transport that has just failed the cross-check: report the other one's figures
-            keep = rs2.transports[0]
-            out["value"] = round(nx * ny * args.steps / runs[keep]["wall_s"] / 1e6, 1)
-            out["ms_per_step"] = round(runs[keep]["wall_s"] * 1e3 / args.steps, 5)
-            out["transport"] = keep
-            out["transport_rejected"] = {"transport": best, "reason": check}
-        if rank == 0:
+        p2.max_iters = n2 + w2 + 256
+        r2 = rank_leg(env, p2, ob2, transports, w2, n2)
+        g2 = {k: v for k, v in r2.items() if "wall_s" in v}
+        if rank == 0 and out is not None and g2:
+            b2 = min(g2, key=lambda k: g2[k]["wall_s"])
             out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat, rows x%d (strong scaling of the reference's "
                                        "largest input)" % world,
-                           "value": round(1024 * 1024 * n2 / res2[b2] / 1e6, 1), "unit": "MLUPS", "steps": n2, "warmup": w2, "transport": b2,
-                           "transports": {k: round(1024 * 1024 * n2 / v / 1e6, 1) for k, v in res2.items()},
-                           "us_per_step": round(res2[b2] / n2 * 1e6, 3), "halo_depth": rs2.sim.get_option("halo_depth"),
-                           "transport_cross_check": check,
-                           "per_rank_launch_set_us": pr2}
-        rs2.sim.close()
-    if world == 1 and rank == 0 and not rank_mode:
-        if extra:
+                           "value": round(1024 * 1024 * n2 / g2[b2]["wall_s"] / 1e6, 1), "unit": "MLUPS", "steps": n2, "warmup": w2, "transport": b2,
+                           "transports": {k: (round(1024 * 1024 * n2 / v["wall_s"] / 1e6, 1) if "wall_s" in v else v) for k, v in r2.items()},
+                           "us_per_step": round(g2[b2]["wall_s"] / n2 * 1e6, 3), "halo_depth": g2[b2]["options"]["halo_depth"],
+                           "per_rank_launch_set_us": g2[b2].get("per_rank")}
+        # ---- BASELINE config 5's weak-scaling leg: every rank holds args.ny rows of an nx x (ny * N) cavity
+        if args.scaling == "strong":
+            nyw = args.ny * world
+            obw = make_workload(args.workload, nx, nyw)
+            nw, ww = min(args.steps, 96), min(args.warmup, 16)
+            pw = lbm_amd.make_params(nx, nyw, nw + ww + 256, 10, 0.1, args.accel, 1.85, obw)
+            rw = rank_leg(env, pw, obw, transports, ww, nw, args.fuse)
+            del obw
+            gw = {k: v for k, v in rw.items() if "wall_s" in v}
+            if rank == 0 and out is not None and gw:
+                bw = min(gw, key=lambda k: gw[k]["wall_s"])
+                out["weak"] = {"workload": "%dx%d %s: %d rows per rank" % (nx, nyw, args.workload, args.ny), "scaling": "weak",
+                               "value": round(nx * nyw * nw / gw[bw]["wall_s"] / 1e6, 1), "unit": "MLUPS", "steps": nw, "warmup": ww,
+                               "ms_per_step": round(gw[bw]["wall_s"] * 1e3 / nw, 5), "transport": bw,
+                               "per_gpu": round(nx * nyw * nw / gw[bw]["wall_s"] / 1e6 / world, 1),
+                               "transports": {k: (round(nx * nyw * nw / v["wall_s"] / 1e6, 1) if "wall_s" in v else v) for k, v in rw.items()},
+                               "per_rank_launch_set_us": gw[bw].get("per_rank")}
+    if world == 1 and rank == 0 and not rank_mode and out is not None and good:
+        if extra and ndev == 1:
             # the reference's own largest input, for the 1024x1024 figure the north star asks for
             p2, ob2 = shipped("1024x1024")
             n2 = 4000
@@ -555,13 +801,24 @@ def main():
             except Exception as e:
                 ref["c_host_input_1024x1024"] = {"error": str(e)[:200]}
             out["reference_rule"] = ref
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nx, ny, obstacles, args.accel)
+    if rank == 0 and out is not None and good:
+        # ---- CPU baseline (rank 0, N = 1 only) and the oracle record `result_ok` is judged on -------------------------
+        if world == 1 and ndev == 1 and not args.no_cpu_baseline and not rank_mode:
+            out["cpu_baseline"] = cpu_baseline(nx, ny, obstacles, args.accel, av_out=av_oracle)
+        if not av_oracle:
+            # no baseline leg in this run: a few steps of the OpenMP build of the same oracle, for the check alone
+            os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, len(os.sched_getaffinity(0)) // max(1, world))))
+            oracle_rate("f32", nx, ny, obstacles, args.accel, 6.0, 8, omp=True, av_out=av_oracle)
+        ok, detail = result_check(good[best]["av"], np.array(av_oracle))
+        out["result_ok"] = ok
+        out["result_check"] = detail
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not ok:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

@@ -88,8 +88,12 @@ int lbm_comm_get_id(void *comm_id_out);
  * straight into the neighbours' halo rows by a push kernel (xGMI peer writes) which then raises a sequence
  * number in the neighbour's flag word; the consumer waits for it with a bounded spin (30 s; reported by lbm_sync
  * as LBM_ERR_COMM) or hipStreamWaitValue32 (option "halo_sync").  lbm_connect_peers is a collective decision:
- * every rank of the ring must call it (or none); lbm_set_option("transport", 1 | 3) switches a connected context
- * that also has a communicator between RCCL send/recv and peer stores.
+ * every rank of the ring must call it (or none).  A context WITHOUT communicator runs on peer stores from then on; a
+ * context that also has an RCCL communicator stays on RCCL send/recv until lbm_set_option("transport", 3) (or default
+ * "transport" = 3 at creation) — peer stores between devices are the caller's explicit choice, to be made once they
+ * have been checked against the RCCL ring on the machine at hand (bench.py: transport_check); "transport" 1 | 3
+ * switches back and forth.  A blob is recognised as "my own process" by a per-process random nonce + boot id, not by
+ * the pid.  A failed call leaves nothing mapped; a repeated call unmaps the previous neighbours first.
  */
 size_t lbm_peer_info_size(void);
 int lbm_peer_info(lbm_ctx *ctx, void *info_out);
@@ -204,9 +208,16 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  register to spare: its non-temporal forms spilled to scratch and were removed).
  *   "transport"    halo transport of a context that carries halo rows: 1 = RCCL send/recv (needs a communicator),
  *                  3 = peer stores (needs connected peers); read-only values 2 = device-to-device copies, 0 = none yet
- *   "halo_sync"    peer transport, consumer side: 0 = wait kernel with a bounded spin (default), 1 = hipStreamWaitValue32,
- *                  2 = the edge tiles / edge chunks of the consuming launch poll the flag words themselves (compact
- *                  launch sets only, elsewhere like 0)
+ *   "halo_sync"    peer transport, consumer side: 0 = wait kernel with a bounded spin (default), 1 = hipStreamWaitValue32
+ *                  (UNBOUNDED: the stream waits for a neighbour that died for ever; diagnostic use), 2 = the edge tiles /
+ *                  edge chunks of the consuming launch poll the flag words themselves (compact launch sets only,
+ *                  elsewhere like 0; refused with LBM_ERR_STATE while a ring neighbour lives on another device or in
+ *                  another process on another device — there the halo rows are read behind the wait kernel's
+ *                  kernel-start acquire)
+ *   "halo_timeout_ms"  bound of that spin, 1..600000 (default 30000).  ONE timeout per run: the first wait that gives up
+ *                  raises the slab's error word and every later wait falls through at once, so the launch sets already
+ *                  queued drain at kernel speed; lbm_sync / lbm_download then return LBM_ERR_COMM and the context
+ *                  accepts only lbm_destroy
  *   "compact"      peer transport: -1/1 = one launch per launch set on one stream, its first workgroups — the edge tiles /
  *                  edge chunks — store the halo rows into the neighbours themselves (LDS-tile kernel, three- / four-step
  *                  kernels, deep window kernel); 0 = edge launch / interior launch / push kernel on two streams

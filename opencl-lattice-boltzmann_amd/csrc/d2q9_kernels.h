@@ -469,11 +469,17 @@ __device__ __forceinline__ const Args *late_args() {
   return reinterpret_cast<const Args *>(p);
 }
 
-// bounded spin on one flag word: gives up after `timeout` ticks of s_memrealtime (100 MHz) and raises the error word
+// bounded spin on one flag word: gives up after `timeout` ticks of s_memrealtime (100 MHz) and raises the error word.
+// ONE timeout per run, not one per launch set: a wait that finds the error word already raised — by an earlier wait of
+// this slab that timed out, in this launch or in any launch before it — falls through at once, so the launch sets still
+// queued behind a neighbour that died drain at kernel speed instead of spinning (sets) x (timeout); lbm_sync reports
+// the failure and the context refuses further work.
 __device__ __forceinline__ void spin_on_flag(const uint32_t *f, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while ((int32_t)(flag_load_system(f) - seq) < 0) {
     __builtin_amdgcn_s_sleep(4);
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
       atomicOr(err, 1u);
       break;

@@ -128,6 +128,7 @@ struct PeerLink {
   float *cells[2] = {nullptr, nullptr};
   uint32_t *flags = nullptr;
   int rows = 0;         // rows the neighbour owns (its top halo starts behind them)
+  bool remote = false;  // another device or another process: stores and flags travel over xGMI / through another L2
   bool ipc = false;     // opened with hipIpcOpenMemHandle: closed in free_slab
   bool connected = false;
 };
@@ -138,11 +139,47 @@ struct PeerInfoBlob {
   int32_t pid, device;
   int32_t rows, row0;
   uint64_t row_stride;
-  uint64_t cells_ptr[2], flags_ptr;   // valid inside process `pid`
+  int32_t pci[4];                     // domain, bus, device of the GPU (+ pad): "is the neighbour on MY device?" across processes,
+                                      // whose device indices may be remapped (HIP_VISIBLE_DEVICES)
+  uint64_t nonce[2];                  // identifies the PROCESS that made the blob (see process_nonce): a pid alone repeats
+                                      // across PID namespaces (containers) and nodes
+  uint64_t cells_ptr[2], flags_ptr;   // valid inside the process with that nonce only
   hipIpcMemHandle_t cells[2], flags;  // for everybody else
 };
-constexpr uint64_t kPeerMagic = 0x4c424d5045455231ull;  // "LBMPEER1"
-constexpr unsigned long long kHaloWaitTicks = 30ull * 100000000ull;  // 30 s of s_memrealtime (100 MHz)
+constexpr uint64_t kPeerMagic = 0x4c424d5045455232ull;  // "LBMPEER2"
+constexpr unsigned long long kHaloWaitMsDefault = 30000;  // consumer-side wait for a neighbour's halo rows: 30 s
+constexpr unsigned long long kTicksPerMs = 100000ull;     // s_memrealtime runs at 100 MHz
+
+// Two random words drawn once per process (/dev/urandom; clock, pid and an address as a fallback) mixed with the host's
+// boot id: "is this blob from my own process, so that its raw pointers are valid here?" must not be answered by the
+// pid, which two containers or two nodes can share.
+const uint64_t *process_nonce() {
+  static uint64_t n[2] = {0, 0};
+  static bool done = false;
+  if (!done) {
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (f) {
+      if (fread(n, sizeof n, 1, f) != 1) n[0] = n[1] = 0;
+      fclose(f);
+    }
+    if (n[0] == 0 && n[1] == 0) {
+      struct timespec ts;
+      clock_gettime(CLOCK_REALTIME, &ts);
+      n[0] = (uint64_t)ts.tv_nsec * 0x9e3779b97f4a7c15ull ^ (uint64_t)ts.tv_sec;
+      n[1] = (uint64_t)getpid() << 32 ^ (uint64_t)(uintptr_t)&n;
+    }
+    uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a of the boot id
+    if (FILE *b = fopen("/proc/sys/kernel/random/boot_id", "r")) {
+      int ch;
+      while ((ch = fgetc(b)) != EOF) h = (h ^ (uint64_t)(unsigned char)ch) * 0x100000001b3ull;
+      fclose(b);
+    }
+    n[1] ^= h;
+    n[0] |= 1;  // never all zero: a zeroed blob matches nobody
+    done = true;
+  }
+  return n;
+}
 
 // unit schedule of one d2q9_step2 launch (see fuse_schedule)
 struct FuseGeom {
@@ -155,6 +192,7 @@ struct FuseGeom {
 
 struct Slab {
   int dev = 0;
+  int cus = 256;          // compute units of the device (hipDeviceProp_t::multiProcessorCount): the schedules plan wave slots from it
   int index = 0;          // position in the global ring of slabs
   int y0 = 0, rows = 0;   // global first row, rows owned
   int row0 = 0;           // halo rows stored below (and above) the owned rows: 0 (one slab), else the halo depth (2 or 8)
@@ -221,6 +259,7 @@ struct lbm_ctx {
   int transport_eff = TRANSPORT_COPY;
   uint32_t halo_seq = 0;    // exchanges issued so far (PEER transport: the value the neighbours' flags reach)
   int halo_sync = 0;        // PEER transport, consumer side: 0 = halo_wait kernel (bounded spin), 1 = hipStreamWaitValue32
+  unsigned long long halo_timeout_ms = kHaloWaitMsDefault;  // bound of that spin (option "halo_timeout_ms")
   int compact = -1;         // PEER transport + d2q9_multi: one launch per launch set on ONE stream, the edge tiles push the
                             // halo rows themselves (-1 auto = on, 0 off = edge stream / interior stream / push kernel)
   bool failed = false;      // a run ended in an error after launches had begun: only lbm_destroy is valid
@@ -392,7 +431,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
   g.nbands = (allow_bands && rows >= 8 * 4 * cmin) ? 8 : 1;
   // CUs x SIMDs x waves per SIMD the kernel's registers / LDS allow, minus the wave slots a concurrent launch needs
   // (slab mode: the edge launch, which must find its slots at once — see slab_geometry)
-  const int waves_resident = std::max(256, 256 * 4 * waves_per_simd - reserve);
+  const int waves_resident = std::max(s.cus, s.cus * 4 * waves_per_simd - reserve);
   // The chunk-pair kernels (d2q9_step3p / d2q9_step4p) hold the LDS of BOTH chunks of a pair until the longer one is
   // done, so a one-round schedule needs an EVEN number of chunks per band that still fits the wave slots: 7.3 slots
   // per band means 6 chunks with 8 bands (82 % of the slots) but 14 with 4 bands (96 %) — take the band count that
@@ -541,7 +580,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     // undivided slab's (23 instead of 27 chunks per strip: 290 against 266 us, lbm_run_profiled).  Here every strip gets
     // n_full chunks of R rows for the slots that are free at once and, as the LAST units of the launch, two shorter
     // chunks of R - (edge iterations) rows: they are dispatched when the edge units retire and finish with the others.
-    const int slots = 256 * 4 * 2, edge_work = 2 * s.strips2, late_per_strip = 2;
+    const int slots = s.cus * 4 * 2, edge_work = 2 * s.strips2, late_per_strip = 2;
     const int n_full = (slots - edge_work) / s.strips2;
     const int rows = i1 - i0, delay = s.edge_rows + 2 * (kDeepSteps - 1);
     const int R = n_full > 0 ? div_up(rows + late_per_strip * delay, n_full + late_per_strip) : 0;
@@ -607,7 +646,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     long best = -1;
     for (int k = 0; k < 3; k++) {
       const long tiles = (long)div_up(c->p.nx, shapes[k][0]) * div_up(s.rows, shapes[k][1]);
-      const long work = (long)div_up(tiles, 256) * updates[k];
+      const long work = (long)div_up(tiles, s.cus) * updates[k];
       if (best < 0 || work < best) { best = work; pick = k; }
     }
     if (c->tile_shape >= 0) pick = std::min(2, c->tile_shape);
@@ -975,7 +1014,7 @@ int wait_halos(lbm_ctx *c, Slab &s, hipStream_t st, uint32_t seq) {
     HIP_TRY(hipStreamWaitValue32(st, s.halo_flags, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
     HIP_TRY(hipStreamWaitValue32(st, s.halo_flags + 1, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
   } else {
-    hipLaunchKernelGGL(halo_wait, dim3(1), dim3(64), 0, st, s.halo_flags, seq, s.halo_flags + 2, kHaloWaitTicks);
+    hipLaunchKernelGGL(halo_wait, dim3(1), dim3(64), 0, st, s.halo_flags, seq, s.halo_flags + 2, c->halo_timeout_ms * kTicksPerMs);
     HIP_TRY(hipGetLastError());
   }
   return LBM_OK;
@@ -1451,8 +1490,8 @@ int sync_all(lbm_ctx *c) {
       if (err) {
         c->failed = true;
         if (err & 2u) return fail(LBM_ERR_COMM, "peer transport: slab %d computed a halo row outside its edge rows (internal error)", s.index);
-        return fail(LBM_ERR_COMM, "peer transport: slab %d waited %d s for a neighbour's halo rows that never came", s.index,
-                    (int)(kHaloWaitTicks / 100000000ull));
+        return fail(LBM_ERR_COMM, "peer transport: slab %d waited %.3g s for a neighbour's halo rows that never came", s.index,
+                    (double)c->halo_timeout_ms * 1e-3);
       }
     }
   }
@@ -1527,6 +1566,11 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   const int nx = c->p.nx, ny = c->p.ny;
   const bool multi = c->halo_mode;
   if (set_dev(s)) return LBM_ERR_HIP;
+  {
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s.dev));
+    if (cus > 0) s.cus = cus;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&s.s_main, hipStreamNonBlocking));
   if (multi) {
     // the edge launch and the halo exchange are the critical path of a launch set (the neighbours wait for
@@ -1608,10 +1652,14 @@ int rebuild_geometry(lbm_ctx *c) {
 }
 
 // ---- peer-halo transport: connecting the ring -------------------------------------------------------
+void device_pci(int dev, int32_t (&pci)[4]);
 void fill_peer_info(const Slab &s, PeerInfoBlob &b, bool with_ipc, hipError_t *ipc_err) {
   memset(&b, 0, sizeof b);
   b.magic = kPeerMagic;
   b.pid = (int32_t)getpid();
+  b.nonce[0] = process_nonce()[0];
+  b.nonce[1] = process_nonce()[1];
+  device_pci(s.dev, b.pci);
   b.device = s.dev;
   b.rows = s.rows;
   b.row0 = s.row0;
@@ -1627,6 +1675,30 @@ void fill_peer_info(const Slab &s, PeerInfoBlob &b, bool with_ipc, hipError_t *i
   }
 }
 
+void device_pci(int dev, int32_t (&pci)[4]) {
+  int v[3] = {-1, -1, -1};
+  if (hipDeviceGetAttribute(&v[0], hipDeviceAttributePciDomainID, dev) != hipSuccess) v[0] = -1;
+  if (hipDeviceGetAttribute(&v[1], hipDeviceAttributePciBusId, dev) != hipSuccess) v[1] = -1;
+  if (hipDeviceGetAttribute(&v[2], hipDeviceAttributePciDeviceId, dev) != hipSuccess) v[2] = -1;
+  (void)hipGetLastError();
+  pci[0] = v[0]; pci[1] = v[1]; pci[2] = v[2]; pci[3] = 0;
+}
+
+bool same_process(const PeerInfoBlob &info) {
+  return info.nonce[0] == process_nonce()[0] && info.nonce[1] == process_nonce()[1] && info.pid == (int32_t)getpid();
+}
+
+// unmap what connect_link opened through HIP IPC (raw-pointer links own nothing)
+void close_link(PeerLink &l) {
+  if (l.ipc) {
+    if (l.cells[0]) hipIpcCloseMemHandle(l.cells[0]);
+    if (l.cells[1]) hipIpcCloseMemHandle(l.cells[1]);
+    if (l.flags) hipIpcCloseMemHandle(l.flags);
+    (void)hipGetLastError();
+  }
+  l = PeerLink{};
+}
+
 int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *which) {
   if (info.magic != kPeerMagic) return fail(LBM_ERR_ARG, "%s neighbour: not a peer descriptor of this library version", which);
   if (info.row_stride != s.row_stride || info.row0 != s.row0)
@@ -1636,8 +1708,8 @@ int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *whi
   if (set_dev(s)) return LBM_ERR_HIP;
   l = PeerLink{};
   l.rows = info.rows;
-  if (info.pid == (int32_t)getpid()) {
-    // same process: the pointers are valid here; another device needs peer access
+  if (same_process(info)) {
+    // same process (nonce, not just the pid): the pointers are valid here; another device needs peer access
     if (info.device != s.dev) {
       int can = 0;
       HIP_TRY(hipDeviceCanAccessPeer(&can, s.dev, info.device));
@@ -1667,12 +1739,21 @@ int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *whi
     l.flags = (uint32_t *)pf;
     l.ipc = true;
   }
+  {
+    // the neighbour's grids live on another GPU unless its PCI address is this slab's (same node: the boot id is in the nonce
+    // only for processes, so compare addresses only; a same-process neighbour is also recognised by its device index)
+    int32_t mine[4];
+    device_pci(s.dev, mine);
+    const bool same_gpu = same_process(info) ? info.device == s.dev
+                                             : (mine[1] >= 0 && mine[0] == info.pci[0] && mine[1] == info.pci[1] && mine[2] == info.pci[2]);
+    l.remote = !same_gpu;
+  }
   l.connected = true;
   return LBM_OK;
 }
 
 // device-side description of a connected slab's neighbours for the fused push / wait of d2q9_multi
-int upload_multi_peer(Slab &s) {
+int upload_multi_peer(const lbm_ctx *c, Slab &s) {
   HaloPeer h{};
   for (int b = 0; b < 2; b++) {
     h.push[0][b] = s.south.cells[b] + (size_t)(s.row0 + s.south.rows) * s.row_stride;
@@ -1683,7 +1764,7 @@ int upload_multi_peer(Slab &s) {
   h.ticket = s.halo_flags + 3;
   h.wait_flags = s.halo_flags;
   h.wait_err = s.halo_flags + 2;
-  h.wait_ticks = kHaloWaitTicks;
+  h.wait_ticks = c->halo_timeout_ms * kTicksPerMs;
   h.push_rows = s.row0;
   h.row_lo0 = s.row0;      // bottom edge rows [row0, 2 row0) -> the south neighbour's top halo rows
   h.row_hi0 = s.rows;      // top edge rows [rows, rows + row0) -> the north neighbour's bottom halo rows
@@ -1702,7 +1783,7 @@ int connect_local_ring(lbm_ctx *c) {
     fill_peer_info(c->slabs[(s.index + 1) % P], no, false, nullptr);
     if (int rc = connect_link(s, s.south, so, "south")) return rc;
     if (int rc = connect_link(s, s.north, no, "north")) return rc;
-    if (int rc = upload_multi_peer(s)) return rc;
+    if (int rc = upload_multi_peer(c, s)) return rc;
   }
   return LBM_OK;
 }
@@ -1759,23 +1840,37 @@ int lbm_connect_peers(lbm_ctx *c, const void *south_info, const void *north_info
   PeerInfoBlob so, no;
   memcpy(&so, south_info, sizeof so);
   memcpy(&no, north_info, sizeof no);
+  // a second call replaces the links: unmap the old ones first (north may alias south's mappings: ipc is false there)
+  close_link(s.north);
+  close_link(s.south);
   PeerLink south, north;
   if (int rc = connect_link(s, south, so, "south")) return rc;
-  if (so.pid == no.pid && so.cells_ptr[0] == no.cells_ptr[0]) {
+  if (so.nonce[0] == no.nonce[0] && so.nonce[1] == no.nonce[1] && so.pid == no.pid && so.cells_ptr[0] == no.cells_ptr[0]) {
     north = south;      // a ring of one or two: the same neighbour on both sides, mapped once
     north.ipc = false;
   } else if (int rc = connect_link(s, north, no, "north")) {
+    const std::string keep = g_err;
+    close_link(south);  // do not leave the south neighbour's grids mapped behind a failed call
+    g_err = keep;
     return rc;
   }
   s.south = south;
   s.north = north;
-  if (int rc = upload_multi_peer(s)) return rc;
-  c->transport_eff = TRANSPORT_PEER;
+  if (int rc = upload_multi_peer(c, s)) return rc;
+  // Which transport runs after a successful connect: peer stores when they are the only one there is (no communicator)
+  // or when the caller asked for them (default "transport" = 3); a context that also holds an RCCL communicator stays on
+  // RCCL send/recv until lbm_set_option("transport", 3) — the caller's explicit decision, e.g. after it has checked the
+  // peer ring against the RCCL ring on its machine (bench.py does: transport_check).
+  if (!s.comm || g_defaults.transport == TRANSPORT_PEER) c->transport_eff = TRANSPORT_PEER;
+  if (c->halo_sync == 2 && (s.south.remote || s.north.remote)) c->halo_sync = 0;  // see lbm_set_option("halo_sync")
   return rebuild_geometry(c);
 }
 
 const char *lbm_last_error(void) { return g_err.c_str(); }
-const char *lbm_version(void) { return "lbm-hip 0.1 (gfx950)"; }
+#ifndef LBM_SRC_ID
+#define LBM_SRC_ID "unknown"
+#endif
+const char *lbm_version(void) { return "lbm-hip 0.3 (gfx950) src " LBM_SRC_ID; }
 
 size_t lbm_comm_id_size(void) { return sizeof(ncclUniqueId); }
 
@@ -2245,8 +2340,23 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
         if (!can) return fail(LBM_ERR_STATE, "device %d cannot wait on memory values", s.dev);
       }
     }
+    if (value == 2)
+      for (const Slab &s : c->slabs)
+        if ((s.south.connected && s.south.remote) || (s.north.connected && s.north.remote))
+          return fail(LBM_ERR_STATE, "halo_sync 2 (the consuming kernel polls the flag words and reads the halo rows without a cache "
+                      "invalidate in between) is accepted only while every ring neighbour lives on this slab's own device: between "
+                      "devices the wait kernel (0) orders the reads behind a kernel-start acquire");
     if (int rc = sync_all(c)) return rc;
     c->halo_sync = (int)value;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "halo_timeout_ms")) {
+    if (value < 1 || value > 600000) return fail(LBM_ERR_ARG, "halo_timeout_ms must be 1..600000");
+    if (int rc = sync_all(c)) return rc;
+    c->halo_timeout_ms = (unsigned long long)value;
+    for (Slab &s : c->slabs)
+      if (s.d_peer && s.south.connected && s.north.connected)
+        if (int rc = upload_multi_peer(c, s)) return rc;
     return LBM_OK;
   }
   if (!strcmp(key, "multistep")) {
@@ -2290,6 +2400,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "halo_sync")) *value = c->halo_sync;
+  else if (!strcmp(key, "halo_timeout_ms")) *value = (long)c->halo_timeout_ms;
   else if (!strcmp(key, "compact")) *value = compact_sets(c);
   else if (!strcmp(key, "halo_depth")) *value = c->halo_mode ? c->halo_depth : 0;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;

@@ -72,6 +72,9 @@ if transport == "peer":
         assert sim.get_option("transport") == 1
         info = sim.peer_info()
         sim.connect_peers(info, info)
+        assert sim.get_option("transport") == 1   # a context with a communicator stays on RCCL until told otherwise
+        sim.connect_peers(info, info)             # a repeated call replaces the links (nothing stays mapped twice)
+        sim.set_option("transport", 3)
         assert sim.get_option("transport") == 3
         sim.upload(cells0)
         sim.run(7)

@@ -96,8 +96,14 @@ print("\n".join(lines))
 if fk is not None and "traffic_bytes" in ev and len(sys.argv) > 6 and sys.argv[6] == "traffic":
     tj_path = os.path.join(P, "traffic.json")
     tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+    # the build these counters belong to: the `library` field of the profiled run's own bench line (lbm_version(): a digest
+    # of the sources); bench.py attaches the entry only to runs of exactly that build
+    version = None
+    for ln in open(os.path.join(G, "prof_%s_stats.log" % tag)):
+        if ln.startswith('{"metric"'):
+            version = json.loads(ln).get("library")
     tj["%dx%d/%s" % (nx, ny, "deep_twin" if "deep_twin" in kern else "deep" if "deep" in kern else "step%d" % per_launch)] = {
-        "hbm_bytes_per_launch": ev["traffic_bytes"], "fetch_size_kib": fk, "write_size_kib": wk,
+        "hbm_bytes_per_launch": ev["traffic_bytes"], "fetch_size_kib": fk, "write_size_kib": wk, "library_version": version,
         "source": "profiles/%s.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of the same bench.py command on %s, FETCH doubled per "
                   "MI355X_MICROARCH.md and checked on a 1 GiB copy)" % (tag, datetime.date.today()),
         "evidence": {k: v for k, v in ev.items() if k != "traffic_bytes"}}
