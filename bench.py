@@ -310,7 +310,7 @@ def profile_all_ranks(env, sim, nsteps, extra):
     return [json.loads(b.decode().strip()) for b in gather_blobs(env.dist, blob, env.world, env.device)]
 
 
-def rank_leg(env, params, obstacles, transports, warmup, steps, fuse=-1, profile=True, want_av=False):
+def rank_leg(env, params, obstacles, transports, warmup, steps, fuse=-1, profile=True, want_av=False, before=None):
     """One workload over the ranks, once per halo transport — a fresh context each, so that a transport that fails
     leaves nothing behind for the next.  Returns {transport: {...}}; a failed transport has an "error" instead of times."""
     runs = {}
@@ -322,6 +322,8 @@ def rank_leg(env, params, obstacles, transports, warmup, steps, fuse=-1, profile
             if fuse >= 0:
                 sim.set_option("fuse", fuse)
             sim.upload(None)  # uniform rest state, built on the device
+            if before:
+                before()      # the declared pre-warm-up (calibration launches), right before the W warm-up steps
             entry["wall_s"], entry["loop_ms"] = timed_run(env, sim, warmup, steps)
             entry["row_range"] = sim.row_range()
             entry["options"] = {k: sim.get_option(k) for k in ("fuse", "pair", "launch_steps", "multistep", "halo_depth")}
@@ -587,12 +589,14 @@ def main():
     params = lbm_amd.make_params(nx, ny, total_steps, 10, 0.1, args.accel, 1.85, obstacles)
     ndev = args.gpus if one_process else 1
 
-    def plain_leg(p, ob, warmup, steps, fuse=-1, want_av=False):
+    def plain_leg(p, ob, warmup, steps, fuse=-1, want_av=False, before=None):
         """one context in this process (one slab, or --launcher one-process: one slab per device)"""
         with (lbm_amd.LBM(p, ob, devices=list(range(ndev))) if ndev > 1 else lbm_amd.LBM(p, ob)) as sim:
             if fuse >= 0:
                 sim.set_option("fuse", fuse)
             sim.upload(None)
+            if before:
+                before()
             e = {}
             e["wall_s"], e["loop_ms"] = timed_run(env, sim, warmup, steps)
             e["row_range"] = sim.row_range()
@@ -617,22 +621,29 @@ def main():
         if "wall_s" in c:
             cold = round(nx * ny * args.steps / c["wall_s"] / 1e6, 1)
 
-    # ---- the two roofline denominators (a float4 copy of 1 GiB each way; packed-FMA issue rate, ~1.9 ms per launch):
-    # measured anyway, and done here they also bring the chip to its working clock before the W warm-up steps
-    copy_gbps = valu_tera = None
-    pre = {"copy_launches": 0, "copy_ms": 0.0, "valu_calib_launches": 0, "valu_calib_ms": 0.0,
-           "what": "calibration launches that run between context creation and the W warm-up steps; `value_cold` is the "
-                   "same W + K steps measured before any of them, in a context of its own"}
-    try:
-        t0 = time.perf_counter()
-        copy_gbps = round(lbm_amd.copy_bandwidth_gbps(1 << 30, args.calib_iters), 1)
-        pre["copy_launches"], pre["copy_ms"] = args.calib_iters, round((time.perf_counter() - t0) * 1e3, 1)
-        if args.valu_calib > 0:
-            t0 = time.perf_counter()
-            valu_tera = round(lbm_amd.valu_rate_tera(args.valu_calib), 2)
-            pre["valu_calib_launches"], pre["valu_calib_ms"] = args.valu_calib, round((time.perf_counter() - t0) * 1e3, 1)
-    except lbm_amd.LBMError:
-        pass
+    # ---- the two roofline denominators (a float4 copy of 1 GiB each way; packed-FMA issue rate, ~1.9 ms per launch) are
+    # measured anyway — and measured BETWEEN the creation of a timed leg's context and its W warm-up steps they also bring
+    # the chip to its working clock (context creation leaves it idle for a second; the first ~40 ms after that run 8-25 %
+    # below the steady state).  That is a warm-up beyond --warmup, so the line says so: `pre_warmup`, and `value_cold`.
+    calib = {"copy_gbps": None, "valu_tera": None}
+    pre = {"copy_launches": 0, "copy_ms": 0.0, "valu_calib_launches": 0, "valu_calib_ms": 0.0, "legs": 0,
+           "what": "calibration launches (1 GiB float4 copy: once; packed-FMA issue rate: before every timed leg) that run "
+                   "between the creation of a leg's context and its W warm-up steps; `value_cold` is the same W + K steps "
+                   "with none of them, in a context of its own, measured first"}
+
+    def pre_warm():
+        try:
+            if calib["copy_gbps"] is None and args.calib_iters > 0:
+                t0 = time.perf_counter()
+                calib["copy_gbps"] = round(lbm_amd.copy_bandwidth_gbps(1 << 30, args.calib_iters), 1)
+                pre["copy_launches"], pre["copy_ms"] = args.calib_iters, round((time.perf_counter() - t0) * 1e3, 1)
+            if args.valu_calib > 0:
+                t0 = time.perf_counter()
+                calib["valu_tera"] = round(lbm_amd.valu_rate_tera(args.valu_calib), 2)
+                pre["valu_calib_launches"], pre["valu_calib_ms"] = args.valu_calib, round((time.perf_counter() - t0) * 1e3, 1)
+                pre["legs"] += 1
+        except lbm_amd.LBMError:
+            pass
 
     # ---- N ranks: every transport against the oracle first; only those that pass are timed ---------------------------
     tcheck, transports = None, [None]
@@ -643,9 +654,11 @@ def main():
 
     # ---- the timed region(s): one per halo transport, the faster one is reported as `value` -----------------------
     if rank_mode:
-        runs = rank_leg(env, params, obstacles, transports, args.warmup, args.steps, args.fuse, want_av=True)
+        runs = rank_leg(env, params, obstacles, transports, args.warmup, args.steps, args.fuse, want_av=True, before=pre_warm)
     else:
-        runs = {"single" if ndev == 1 else "one-process": plain_leg(params, obstacles, args.warmup, args.steps, args.fuse, want_av=True)}
+        runs = {"single" if ndev == 1 else "one-process": plain_leg(params, obstacles, args.warmup, args.steps, args.fuse, want_av=True,
+                                                                    before=pre_warm)}
+    copy_gbps, valu_tera = calib["copy_gbps"], calib["valu_tera"]
     good = {k: v for k, v in runs.items() if "wall_s" in v}
 
     out, ok = None, False
@@ -706,7 +719,7 @@ def main():
         p2, ob2 = shipped("1024x1024")
         n2, w2 = 4000, 400
         p2.max_iters = n2 + w2 + 256
-        r2 = rank_leg(env, p2, ob2, transports, w2, n2)
+        r2 = rank_leg(env, p2, ob2, transports, w2, n2, before=pre_warm)
         g2 = {k: v for k, v in r2.items() if "wall_s" in v}
         if rank == 0 and out is not None and g2:
             b2 = min(g2, key=lambda k: g2[k]["wall_s"])
@@ -722,7 +735,7 @@ def main():
             obw = make_workload(args.workload, nx, nyw)
             nw, ww = min(args.steps, 96), min(args.warmup, 16)
             pw = lbm_amd.make_params(nx, nyw, nw + ww + 256, 10, 0.1, args.accel, 1.85, obw)
-            rw = rank_leg(env, pw, obw, transports, ww, nw, args.fuse)
+            rw = rank_leg(env, pw, obw, transports, ww, nw, args.fuse, before=pre_warm)
             del obw
             gw = {k: v for k, v in rw.items() if "wall_s" in v}
             if rank == 0 and out is not None and gw:

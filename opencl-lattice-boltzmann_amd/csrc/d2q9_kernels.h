@@ -31,6 +31,7 @@
 // wave64 shuffles), different arithmetic grouping (pairwise momentum differences, shared
 // equilibrium terms), fused accelerate, byte mask, deterministic two-stage reduction.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1642,7 +1643,9 @@ struct PairLoads {
   float h0, h1, h2;  // lane 0: west neighbours of planes 1,5,8; lane 63: east neighbours of planes 3,6,7
   uint32_t m;        // the aligned 4 mask bytes that hold the two cells' (bytes 0,1 or 2,3: see deep_sweep's mask_shift)
 };
-template <bool NTL>
+// HALO = false: no neighbour elements for lanes 0 and 63 (the strip's halo lanes cover the depth without them, see
+// deep_edge_loads)
+template <bool NTL, bool HALO = true>
 __device__ __forceinline__ void issue_pair_loads(const Step2Args &a, int r, int xcol, int xhalo_w, int xhalo_e, int lane, PairLoads &in) {
   const size_t ps = a.plane_stride, rs = a.row_stride;
   const int r_s = (r == 0) ? a.ny - 1 : r - 1;
@@ -1659,7 +1662,7 @@ __device__ __forceinline__ void issue_pair_loads(const Step2Args &a, int r, int 
   // the load, and the wait for the load with it)
   in.m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)r * a.nx + (xcol & ~3));
   in.h0 = in.h1 = in.h2 = 0.f;
-  if (lane == 0 || lane == 63) {
+  if (HALO && (lane == 0 || lane == 63)) {
     const bool lo = (lane == 0);
     in.h0 = lo ? Rc[1 * ps + xhalo_w] : Rc[3 * ps + xhalo_e];
     in.h1 = lo ? Rs[5 * ps + xhalo_w] : Rs[6 * ps + xhalo_e];
@@ -1683,6 +1686,11 @@ __device__ __forceinline__ v2f lds_pair_shifted(const float *p) {  // 4-byte ali
 __device__ __forceinline__ void lds_pair_put(float *p, v2f v) { *reinterpret_cast<v2f *>(p) = v; }
 
 constexpr int deep_halo_lanes(int D) { return D / 2; }           // ceil((D-1)/2) lanes of two cells at either end of a strip
+// Does level 0 need the element beyond the strip's first / last cell (an extra load by lanes 0 and 63)?  Level l's output
+// is valid from cell l + (0 with that element, 1 without) inwards; the owned cells start at cell 2*HL: with an even depth
+// the halo lanes cover the D levels without it (D = 8: 8 halo cells, levels 0..7 invalidate cells 0..7), an odd depth
+// (the twins' D = 5: 4 halo cells) needs it.
+constexpr bool deep_edge_loads(int D) { return 2 * deep_halo_lanes(D) < D; }
 constexpr int deep_lds_windows(int D) { return D - 1 < 4 ? D - 1 : 4; }  // 4 x 4.5 KB + 1 register window: two waves per SIMD
 
 // TWIN (d2q9_deep_twin): the wave is one of the two of a workgroup that work on the chunks 2p (sweeping down) and 2p+1
@@ -1694,12 +1702,15 @@ constexpr int deep_lds_windows(int D) { return D - 1 < 4 ? D - 1 : 4; }  // 4 x 
 // Levels whose window lives in registers receive the twin's row through a MAILBOX of three slots behind the wave's
 // windows: written in iteration l-1, read in iteration l (early: with the window reads of the level before), and a
 // barrier at the start of level l keeps the twin's next write (level l+1, later in the same iteration) behind that read.
-template <int D, int WL, bool UP, bool NT, bool OBST_PATHS, bool TWIN = false>
-__device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, float *lds, float *partials, int pstride, int ys, int ye,
+template <int D, int WL, bool UP, bool NT, bool OBST_PATHS, bool TWIN = false, int LT = 0>
+__device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L_arg, float *lds, float *partials, int pstride, int ys, int ye,
                                            int xcol, int xhalo_w, int xhalo_e, int lane, bool owner, int unit,
                                            const bool twinned_in = false, float *lds_twin = nullptr) {
   // L = timesteps this launch advances (2 .. D, wave-uniform): the run's last launches are shallower.  All row
-  // arithmetic is in terms of L; D bounds the unrolled level loop and fixes the halo lanes.
+  // arithmetic is in terms of L; D bounds the unrolled level loop and fixes the halo lanes.  LT > 0: a kernel
+  // instantiated for launches of exactly LT timesteps (the host passes nlev == LT).
+  static_assert(LT >= 0 && LT <= D, "steady depth");
+  const int L = LT > 0 ? LT : L_arg;
   const bool twinned = TWIN && twinned_in;  // wave-uniform; a wave whose twin has no rows runs alone
   const size_t ps = a.plane_stride;
   auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
@@ -1708,12 +1719,12 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
   const int sf = twinned ? 1 : 2;           // level l is active from iteration sf*l on
   const int r0 = UP ? ys - lead : ye - 1 + lead;  // level 0 works on row r0 + k*d in iteration k = 0 .. last,
   const int last = n + lead + (L - 1) - 1;        // level l on row r0 + (k-l)*d
-  v2f sum[D];
+  float sum[D];  // per level: |j|/rho over the lane's two cells (one register per level: a pair each cost 8 VGPRs the steady form needs)
   constexpr int NR = (D - 1 - WL) > 0 ? (D - 1 - WL) : 1;
   PairWindow w[NR];
   uint32_t m_mid[D - 1];
 #pragma unroll
-  for (int l = 0; l < D; l++) sum[l] = splat2(0.f);
+  for (int l = 0; l < D; l++) sum[l] = 0.f;
 #pragma unroll
   for (int l = 0; l < D - 1; l++) m_mid[l] = 0;
 #pragma unroll
@@ -1726,7 +1737,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
   const uint32_t accmask = a.accel_next ? 0xffffffffu : ~(1u << (L - 1));  // the last level's output is the stored state
   const uint32_t mask_shift = (xcol & 2) * 8;  // nx % 4 == 0: the pair's two mask bytes are the low or the high half of a dword
   PairLoads in;
-  issue_pair_loads<false>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, in);
+  issue_pair_loads<false, deep_edge_loads(D)>(a, wrap(r0), xcol, xhalo_w, xhalo_e, lane, in);
   // the six window planes level l (1 .. D-1) gathers from: middle row (0, 1 from the west, 3 from the east) and trail row
   float *const mailbox = lw + WL * kPairWinFloats;  // (twins with register windows only)
   auto window_read = [&](int l, int par, int k, v2f (&q)[6]) __attribute__((always_inline)) {
@@ -1759,47 +1770,64 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
       }
     }
   };
-  for (int k = 0; k <= last; k++) {
+  // One row iteration.  lt_tag 0: the general form — the depth L is a run-time value, a level runs once its first row has
+  // arrived (`active`), the level chain ends with a `break`.  lt_tag > 0: the STEADY form for launches of exactly that many
+  // timesteps, valid once every level is active (k > sf*(L-1)): depth, activity and "is this the last level" are
+  // compile-time facts, so the chain of levels is straight-line code — `nxt` of one level IS `top` of the next (a
+  // renaming, where the general form's control flow made the compiler copy nine register pairs per level, ~20 % of its
+  // VALU instructions), the last level's row lands in `out` where it is produced, and the start-up branches, the twins'
+  // hand-overs and their barriers are gone.  Both forms do the same arithmetic in the same order on every cell.
+  auto iteration = [&](const int k, auto lt_tag) __attribute__((always_inline)) {
+    constexpr int LS = decltype(lt_tag)::value;
+    constexpr bool STEADY = LS > 0;
+    const int LL = STEADY ? LS : L;
     const int par = k & 1;
     v2f top[9], pre[2][6];  // pre[l & 1]: the window planes of level l, read one level ahead
     uint32_t m_top;
     const int row0 = wrap(r0 + k * d);
     accbits = ((accbits << 1) | ((row0 == a.accel_row || row0 == a.accel_row_b) ? 1u : 0u)) & accmask;
     ownbits = (ownbits << 1) | ((k >= lead && k <= n + lead - 1) ? 1u : 0u);
-    if (k >= sf) window_read(1, par, k, pre[1]);  // issued before level 0's arithmetic: the LDS latency hides behind it
+    if (STEADY || k >= sf) window_read(1, par, STEADY ? -1 : k, pre[1]);  // issued before level 0's arithmetic: the LDS latency hides behind it
     {  // level 0: step t+1 of row0 from the loaded source rows
       v2f g[9];
       g[0] = in.c[0]; g[2] = in.c[2]; g[4] = in.c[4];
-      g[1] = pair_from_west(in.c[1], in.h0); g[5] = pair_from_west(in.c[5], in.h1); g[8] = pair_from_west(in.c[8], in.h2);
-      g[3] = pair_from_east(in.c[3], in.h0); g[6] = pair_from_east(in.c[6], in.h1); g[7] = pair_from_east(in.c[7], in.h2);
+      if (deep_edge_loads(D)) {
+        g[1] = pair_from_west(in.c[1], in.h0); g[5] = pair_from_west(in.c[5], in.h1); g[8] = pair_from_west(in.c[8], in.h2);
+        g[3] = pair_from_east(in.c[3], in.h0); g[6] = pair_from_east(in.c[6], in.h1); g[7] = pair_from_east(in.c[7], in.h2);
+      } else {
+        g[1] = pair_from_west(in.c[1]); g[5] = pair_from_west(in.c[5]); g[8] = pair_from_west(in.c[8]);
+        g[3] = pair_from_east(in.c[3]); g[6] = pair_from_east(in.c[6]); g[7] = pair_from_east(in.c[7]);
+      }
       m_top = in.m >> mask_shift;  // (bits 16.. may hold the neighbouring pair's bytes: every test masks)
       v2f t;
       if (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_top & 0xffffu) != 0) == 0ull) t = collide2<false>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
       else t = collide2<true>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
-      if ((ownbits & 1u) && owner) sum[0] += t;
+      if ((ownbits & 1u) && owner) sum[0] += t.x + t.y;
       // The row the last level finished in the PREVIOUS iteration is stored here, right before this iteration's loads:
       // the wave waits for its loads at the top of the next iteration with the memory counter at zero, stores
       // included — with the stores at the end of an iteration that wait exposed the round trip of stores just issued;
       // now everything it covers was issued a whole iteration of arithmetic earlier.
       // (stores and loads issued BEFORE level 0's arithmetic, right after its gather: 1 % slower everywhere, tools/ab.py --libs)
-      if (k - 1 >= sf * (L - 1)) store_row(k - 1);
+      if (STEADY || k - 1 >= sf * (LL - 1)) store_row(k - 1);
       // (unconditional: the last iteration loads its own row once more rather than branching around the loads)
-      issue_pair_loads<false>(a, wrap(r0 + (k < last ? k + 1 : k) * d), xcol, xhalo_w, xhalo_e, lane, in);
+      issue_pair_loads<false, deep_edge_loads(D)>(a, wrap(r0 + (k < last ? k + 1 : k) * d), xcol, xhalo_w, xhalo_e, lane, in);
     }
 #pragma unroll
     for (int l = 1; l < D; l++) {
-      const bool final = (l == D - 1) || (l == L - 1);  // (level l exists: the level before it was not the last)
-      if (TWIN && (l - 1) >= WL && twinned && k == l) __syncthreads();  // mailbox read (above) before the twin's next write
+      if (STEADY && l >= LS) break;  // (compile-time: the unrolled chain ends here)
+      if (STEADY) __builtin_amdgcn_sched_barrier(0);  // one level after the other: interleaved levels cost hundreds of spilled registers
+      const bool final = (l == D - 1) || (l == LL - 1);  // (level l exists: the level before it was not the last)
+      if (!STEADY && TWIN && (l - 1) >= WL && twinned && k == l) __syncthreads();  // mailbox read (above) before the twin's next write
       v2f nxt[9];
       uint32_t m_nxt = 0;
-      const bool active = k >= sf * l;
+      const bool active = STEADY || k >= sf * l;
       const bool in_lds = (l - 1) < WL;
       float *const W = lw + (l - 1) * kPairWinFloats;
       float *const Wp = W + (3 + 3 * par) * kPairSlotFloats;
       PairWindow &R = w[in_lds ? 0 : (l - 1 - WL)];
       if (active) {
         const v2f (&q)[6] = pre[l & 1];
-        if (l + 1 < D && !final && k >= sf * (l + 1)) window_read(l + 1, par, k, pre[(l + 1) & 1]);  // the next level's window, early
+        if (l + 1 < D && !final && (STEADY || k >= sf * (l + 1))) window_read(l + 1, par, STEADY ? -1 : k, pre[(l + 1) & 1]);  // the next level's window, early
         v2f g[9];
         g[0] = q[0]; g[1] = q[1]; g[3] = q[2];
         if (UP) {  // the trail row is the row below: its planes 2,5,6 arrive; the newest row is above: 4,7,8
@@ -1815,9 +1843,9 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
         if (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_nxt & 0xffffu) != 0) == 0ull) t = collide2<false>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
         else t = collide2<true>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
         if (!final) {
-          if (((ownbits >> l) & 1u) && owner) sum[l] += t;
+          if (((ownbits >> l) & 1u) && owner) sum[l] += t.x + t.y;
         } else {  // the last level: every row it works on is one of the chunk's own; stored in the NEXT iteration
-          if (owner) sum[l] += t;
+          if (owner) sum[l] += t.x + t.y;
 #pragma unroll
           for (int kk = 0; kk < 9; kk++) out[kk] = nxt[kk];
         }
@@ -1835,7 +1863,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
         R.S1[0] = UP ? top[2] : top[4]; R.S1[1] = UP ? top[5] : top[8]; R.S1[2] = UP ? top[6] : top[7];
       }
       m_mid[l - 1] = m_top;
-      if (TWIN && twinned && k == l - 1) {
+      if (!STEADY && TWIN && twinned && k == l - 1) {
         // `top` is the first row of level l-1: its planes that move the twin's way become the trail row of the twin's
         // first gather of level l, next iteration (the twin reads parity l & 1 then; its own puts reach that slot later;
         // a register window: through the twin's mailbox)
@@ -1851,13 +1879,28 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L, floa
         m_top = m_nxt;
       }
     }
-    if (TWIN && twinned && k <= L - 2) __syncthreads();  // both twins run these iterations; the hand-over of iteration k is read in k+1
+    if (!STEADY && TWIN && twinned && k <= L - 2) __syncthreads();  // both twins run these iterations; the hand-over of iteration k is read in k+1
+  };
+  // start-up in the general form (level l joins in iteration sf*l), then — for the depths whole runs are cut into — the
+  // steady form to the end of the chunk; other depths (the shallow launches at the end of a run) stay general
+  // Start-up in the general form (level l joins in iteration sf*l), then the steady form to the end of the chunk.  The
+  // steady form exists in kernels instantiated for ONE depth (LT > 0: the launch advances exactly LT timesteps, L is
+  // that constant); LT = 0 is the kernel for any depth, general form throughout.  (Tried and dropped: all depths in one
+  // kernel — one loop per form: what the later loops hoist is live through the earlier ones, 600 spilled registers;
+  // one loop that picks its body per iteration: 44-206.)
+  const int k_steady = sf * (L - 1) + 1;
+  int k = 0;
+  if (LT > 0) {
+    for (; k < k_steady && k <= last; k++) iteration(k, std::integral_constant<int, 0>{});
+    for (; k <= last; k++) iteration(k, std::integral_constant<int, LT>{});
+  } else {
+    for (; k <= last; k++) iteration(k, std::integral_constant<int, 0>{});
   }
   store_row(last);
 #pragma unroll
   for (int l = 0; l < D; l++) {
     if (l >= L) break;
-    const float s = wave_sum(sum[l].x + sum[l].y);
+    const float s = wave_sum(sum[l]);
     if (lane == 0) partials[(size_t)l * pstride + unit] = s;
   }
 }
@@ -1902,7 +1945,7 @@ __device__ __forceinline__ void push_chunk_pairs(const Step2Args *la, int ys, in
 
 // PUSH: the kernel as ONE launch per launch set of a slab (compact launch sets, see Step2Args): the first edge_units
 // workgroups work through the edge schedule, push their rows into the ring neighbours and raise the flag words.
-template <int D, bool NT, bool OBST_PATHS = false, bool PUSH = false>
+template <int D, bool NT, bool OBST_PATHS = false, bool PUSH = false, int LT = 0>
 __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *partials, int pstride, int nlev) {
   constexpr int WL = deep_lds_windows(D), HL = deep_halo_lanes(D);
   __shared__ float lds[WL * kPairWinFloats + 4];
@@ -1941,9 +1984,9 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
   const int xhalo_e = (xcol + 2 >= a.nx) ? 0 : xcol + 2;
   // even chunks sweep up, odd chunks down: neighbouring chunks meet at their common boundary rows at about the same time
   if (__builtin_amdgcn_readfirstlane((int)((chunk & 1) == 0)))
-    deep_sweep<D, WL, true, NT, OBST_PATHS>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+    deep_sweep<D, WL, true, NT, OBST_PATHS, false, LT>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
   else
-    deep_sweep<D, WL, false, NT, OBST_PATHS>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+    deep_sweep<D, WL, false, NT, OBST_PATHS, false, LT>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
   if constexpr (PUSH) {
     const Step2Args *la = late_args<Step2Args>();
     if (do_push) {

@@ -279,6 +279,8 @@ struct lbm_ctx {
   int pair = -1;            // d2q9_step3p (chunk pairs share their start-up rows): 1 on, 0 off, -1 auto
   int twin_steps = 0;       // d2q9_deep_twin: most timesteps per launch (2..8), 0 = auto (5)
   int edge_aware = -1;      // d2q9_deep with row slabs: one-round interior schedule whose last units take over the edge launch's slots (-1/1 on, 0 off)
+  int steady = -1;          // d2q9_deep: 1 (and -1, auto) = launches of 6, 7 or 8 timesteps run the kernel instantiated for that depth (steady
+                            // form of the row loop), 0 = the any-depth kernel always
   int obst_paths = -1;      // d2q9_deep: 1 (and -1, auto) = a second collision path without bounce-back selects for waves without blocked cells
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
@@ -889,7 +891,12 @@ void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, int units
   a.lanes_out = s.lanes2;
   const dim3 grid(units), block(64);
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;  // (-1 auto = on)
-  if (nt && paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  // the depths whole runs are cut into have a kernel of their own (steady form of the row loop, see deep_sweep); the
+  // default configuration only — every other combination of options runs the any-depth kernel
+  if (nt && paths && c->steady != 0 && nlev == 8) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, false, 8>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths && c->steady != 0 && nlev == 7) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, false, 7>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths && c->steady != 0 && nlev == 6) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, false, 6>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -902,7 +909,10 @@ void launch_deep_compact(const lbm_ctx *c, const Slab &s, const Step2Args &a0, f
   a.lanes_out = s.lanes2;
   const dim3 grid(a0.edge_units + s.f6_main.units), block(64);
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;
-  if (nt && paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  if (nt && paths && c->steady != 0 && nlev == 8) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true, 8>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths && c->steady != 0 && nlev == 7) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true, 7>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths && c->steady != 0 && nlev == 6) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true, 6>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (paths) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else hipLaunchKernelGGL((d2q9_deep<kDeepSteps, false, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -2286,6 +2296,11 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     c->edge_aware = (int)value;
     return rebuild_geometry(c);
   }
+  if (!strcmp(key, "steady")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "steady must be -1 (auto), 0 or 1");
+    c->steady = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "obst_paths")) {
     if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "obst_paths must be -1 (auto), 0 or 1");
     c->obst_paths = (int)value;
@@ -2399,6 +2414,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   }
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
+  else if (!strcmp(key, "steady")) *value = c->steady != 0;
   else if (!strcmp(key, "halo_sync")) *value = c->halo_sync;
   else if (!strcmp(key, "halo_timeout_ms")) *value = (long)c->halo_timeout_ms;
   else if (!strcmp(key, "compact")) *value = compact_sets(c);

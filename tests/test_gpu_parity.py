@@ -869,8 +869,9 @@ def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, 
 @pytest.mark.parametrize("nx,ny,chunk", [(256, 32, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (260, 33, 4), (8192, 32, 8),
                                          (1024, 300, 128), (2048, 130, 0), (1000, 77, 9)])
 @pytest.mark.parametrize("nsteps", [2, 3, 6, 7, 8, 13, 20, 23])
-@pytest.mark.parametrize("depth,obst_paths,pair", [(6, 0, 0), (8, 1, 0), (8, 0, 1), (7, 1, 1), (8, 1, -1)])
-def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, depth, obst_paths, pair):
+@pytest.mark.parametrize("depth,obst_paths,pair,nt", [(6, 0, 0, -1), (8, 1, 0, -1), (8, 0, 1, -1), (7, 1, 1, -1), (8, 1, -1, -1),
+                                                      (8, 1, 0, 1), (7, 1, 0, 1), (6, 1, 0, 1)])
+def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, depth, obst_paths, pair, nt):
     """d2q9_deep (up to eight timesteps per launch; lanes of two cells, explicit packed collision, four LDS windows + up to
     three register windows, x-shifted planes read back from LDS already shifted; obst_paths = 1: a second collision path
     without the bounce-back selects for waves that hold no blocked cell): bit-identical to single steps; a run's steps are
@@ -878,7 +879,10 @@ def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, dept
     is its limit), a single left-over step goes to the single-step kernel.  pair = 1: d2q9_deep_twin, two waves per
     workgroup on the chunks 2p / 2p+1 of a strip that start at their common boundary and hand each other their first row
     of every level (five steps per launch by default, up to eight with option twin_steps: the levels whose window lives in
-    registers then receive the twin's row through an LDS mailbox); -1 = where the library pairs by itself"""
+    registers then receive the twin's row through an LDS mailbox); -1 = where the library pairs by itself.
+    nt = 1 (non-temporal stores, as on the grids this kernel is the default for): launches of exactly 6, 7 or 8 timesteps run
+    the kernel instantiated for that depth — general form of the row loop while the levels start up, then the steady form
+    whose level chain is straight-line code (option "steady", on by default)"""
     rng = np.random.default_rng(6 * nx + ny + nsteps)
     ob, cells0 = random_case(rng, nx, ny)
     if obst_paths:
@@ -886,7 +890,9 @@ def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, dept
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     with lbm.LBM(p, ob) as sim:
-        opts = {"multistep": 0, "fuse": depth, "chunk_rows": chunk, "obst_paths": obst_paths, "pair": pair}
+        opts = {"multistep": 0, "fuse": depth, "chunk_rows": chunk, "obst_paths": obst_paths, "pair": pair, "nt_stores": nt}
+        if nt == 1:
+            assert sim.get_option("steady") == 1
         if pair == 1:
             opts["twin_steps"] = depth   # twins of 7 / 8 steps per launch: the register windows' first rows go through the mailbox
         for k, v in opts.items():
