@@ -1417,8 +1417,10 @@ __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *
   int qw = qcol % q4;
   if (qw < 0) qw += q4;
   const int xcol = qw * 4;
-  const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
-  const int xhalo_e = (xcol + 4 >= a.nx) ? 0 : xcol + 4;
+  // (ONE register for both: only lane 0 reads the element west of its strip, only lane 63 the one east of it — the
+  // compact-set form of this kernel sat two registers over the limit, 12 bytes of scratch per lane)
+  const int xhalo_w = (lane == 0) ? ((xcol == 0) ? a.nx - 1 : xcol - 1) : ((xcol + 4 >= a.nx) ? 0 : xcol + 4);
+  const int xhalo_e = xhalo_w;
   const size_t ps = a.plane_stride;
   auto wrap = [&](int r) { return r < 0 ? r + a.ny : (r >= a.ny ? r - a.ny : r); };
   const bool up = wv != 0;
@@ -1538,7 +1540,13 @@ __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *
   if constexpr (PUSH) {
     const Step2Args *la = late_args<Step2Args>();
     if (do_push) {
-      push_chunk(la, ys, ye, xcol, owner);
+      // the lane's column once more, from the lane number (hidden from common-subexpression elimination): kept from the
+      // top of the kernel its 64-bit form was live across the row loop — the two registers this kernel spilled
+      int lane2 = (int)(threadIdx.x & 63);
+      asm volatile("" : "+v"(lane2));
+      int qw2 = (strip * la->lanes_out + lane2 - 2) % q4;
+      if (qw2 < 0) qw2 += q4;
+      push_chunk(la, ys, ye, qw2 * 4, owner);
       publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
     }
   }
@@ -1651,16 +1659,26 @@ __device__ __forceinline__ void issue_pair_loads(const Step2Args &a, int r, int 
   const int r_s = (r == 0) ? a.ny - 1 : r - 1;
   const int r_n = (r == a.ny - 1) ? 0 : r + 1;
   const float *Rc = a.src + (size_t)r * rs, *Rs = a.src + (size_t)r_s * rs, *Rn = a.src + (size_t)r_n * rs;
+  // (wave-uniform row pointer) + (the lane's 32-bit unsigned byte offset): the SGPR-base form of global_load — the plane
+  // offsets are scalar additions and no load needs a 64-bit vector address (ten v_lshl_add_u64 per row otherwise); the asm
+  // keeps the 32->64-bit extension of the offset next to its uses (instruction selection works per basic block and only
+  // then recognises base + zext(offset)), as in issue_row_loads_sbase
+  unsigned xb = (unsigned)xcol * 4u;
+  asm volatile("" : "+v"(xb));
   auto ld = [&](const float *p) {
-    if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p + xcol));
-    return *reinterpret_cast<const v2f *>(p + xcol);
+    if (NTL) return __builtin_nontemporal_load(reinterpret_cast<const v2f *>(at_byte(p, xb)));
+    return *reinterpret_cast<const v2f *>(at_byte(p, xb));
   };
   in.c[0] = ld(Rc); in.c[1] = ld(Rc + ps); in.c[3] = ld(Rc + 3 * ps);
   in.c[2] = ld(Rs + 2 * ps); in.c[5] = ld(Rs + 5 * ps); in.c[6] = ld(Rs + 6 * ps);
   in.c[4] = ld(Rn + 4 * ps); in.c[7] = ld(Rn + 7 * ps); in.c[8] = ld(Rn + 8 * ps);
   // (a whole aligned dword, shifted after loads_ready(): a 16-bit load gets its zero-extension scheduled right behind
   // the load, and the wait for the load with it)
-  in.m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)r * a.nx + (xcol & ~3));
+  {
+    unsigned mb = (unsigned)(xcol & ~3);
+    asm volatile("" : "+v"(mb));
+    in.m = *reinterpret_cast<const uint32_t *>(a.mask + (size_t)r * a.nx + mb);
+  }
   in.h0 = in.h1 = in.h2 = 0.f;
   if (HALO && (lane == 0 || lane == 63)) {
     const bool lo = (lane == 0);
@@ -1673,6 +1691,7 @@ __device__ __forceinline__ void issue_pair_loads(const Step2Args &a, int r, int 
 // A window of the deep kernel: slot s holds one v2f per lane at float (s*128 + 2*lane); slots 0..2 = planes 0,1,3 of
 // the middle row, slots 3+3p .. 5+3p = the three sweep-direction planes of the rows of parity p (written in iteration
 // k, read as the trail row in iteration k+2).  The register form keeps the two trail rows as S0 (older) and S1.
+typedef __attribute__((address_space(1))) v2f global_v2f;
 constexpr int kPairSlotFloats = 128;
 constexpr int kPairWinFloats = 9 * kPairSlotFloats;
 struct PairWindow { v2f mid[3], S0[3], S1[3]; };
@@ -1762,11 +1781,19 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L_arg, 
   for (int kk = 0; kk < 9; kk++) out[kk] = splat2(0.f);
   auto store_row = [&](int kprev) __attribute__((always_inline)) {
     if (owner) {
-      float *dp = a.dst + (size_t)(r0 + (kprev - (L - 1)) * d) * a.row_stride + xcol;
+      // SGPR-base form again: uniform pointer to the row's plane + the lane's byte offset
+      float *const row = a.dst + (size_t)(r0 + (kprev - (L - 1)) * d) * a.row_stride;
+      unsigned xb = (unsigned)xcol * 4u;
+      asm volatile("" : "+v"(xb));
 #pragma unroll
       for (int kk = 0; kk < 9; kk++) {
-        if (NT) __builtin_nontemporal_store(out[kk], reinterpret_cast<v2f *>(dp + kk * ps));
-        else *reinterpret_cast<v2f *>(dp + kk * ps) = out[kk];
+        // (the plane's row pointer made opaque in scalar registers: otherwise the compiler shares row + offset among the nine
+        // stores as ONE 64-bit vector address and adds the plane offsets to it, eight v_lshl_add_u64)
+        unsigned long long pk = (unsigned long long)(row + kk * ps);
+        asm volatile("" : "+s"(pk));
+        global_v2f *const q = (global_v2f *)(pk + xb);  // (a pointer known to be global memory: global_store with an SGPR base)
+        if (NT) __builtin_nontemporal_store(out[kk], q);
+        else *q = out[kk];
       }
     }
   };
