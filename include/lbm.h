@@ -118,6 +118,16 @@ int lbm_set_default(const char *key, long value);
 int lbm_upload(lbm_ctx *ctx, const float *cells);
 
 /*
+ * Host -> device copy of the obstacle map: replaces clEnqueueWriteBuffer(obstacles) (d2q9-bgk.c:205-209).  lbm_create
+ * has already taken the map it was given (it needs it to lay out the slabs); this entry point exists so that a host
+ * that follows the reference's timing rule — everything from the first host->device transfer to the last read-back
+ * inside the timed region, d2q9-bgk.c:196-263 — can have the obstacle transfer inside it, and so that a caller may
+ * change the map between runs (same nx, ny; params.free_cells_inv is the caller's to keep consistent: it was fixed
+ * at lbm_create).  obstacles = int32[ny][nx] of the GLOBAL grid, borrowed.  Synchronises.
+ */
+int lbm_upload_obstacles(lbm_ctx *ctx, const int32_t *obstacles);
+
+/*
  * Advance nsteps timesteps (accelerate_flow + timestep + av_vels reduction each); asynchronous.
  * Replaces the loop body d2q9-bgk.c:221-238 (accelerate_flow(), timestep(), reduce() wrappers,
  * d2q9-bgk.c:282-393).  May be called repeatedly; after n calls' worth of steps exactly that many

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "lbm_run_timed", "lbm_sync", "lbm_download", "lbm_steps_done", "lbm_row_range", "lbm_final_state",
     "lbm_reynolds", "lbm_set_option", "lbm_get_option", "lbm_copy_bandwidth", "lbm_valu_rate", "lbm_destroy",
     "lbm_last_error", "lbm_version", "lbm_set_default", "lbm_peer_info_size", "lbm_peer_info", "lbm_connect_peers",
-    "lbm_run_profiled",
+    "lbm_run_profiled", "lbm_upload_obstacles",
 ]
 
 TRANSPORTS = {"auto": 0, "rccl": 1, "copy": 2, "peer": 3}
@@ -66,6 +66,7 @@ def load_library():
     L.lbm_comm_id_size.restype = ctypes.c_size_t
     L.lbm_comm_get_id.argtypes = [vp]
     L.lbm_upload.argtypes = [vp, vp]
+    L.lbm_upload_obstacles.argtypes = [vp, vp]
     L.lbm_run.argtypes = [vp, ci]
     L.lbm_run_timed.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
     L.lbm_run_profiled.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
@@ -218,6 +219,13 @@ class LBM:
             c = np.ascontiguousarray(cells, dtype=np.float32)
             assert c.shape == (9, self.ny, self.nx)
             _check(self.lib.lbm_upload(self.ctx, c.ctypes.data), "lbm_upload")
+
+    def upload_obstacles(self, obstacles):
+        """the obstacle map once more (d2q9-bgk.c:205-209); same shape as at creation"""
+        ob = np.ascontiguousarray(obstacles, dtype=np.int32)
+        assert ob.shape == (self.ny, self.nx)
+        _check(self.lib.lbm_upload_obstacles(self.ctx, ob.ctypes.data), "lbm_upload_obstacles")
+        self.obstacles = ob
 
     def run(self, nsteps):
         _check(self.lib.lbm_run(self.ctx, nsteps), "lbm_run")

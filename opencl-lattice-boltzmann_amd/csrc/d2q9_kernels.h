@@ -2026,7 +2026,7 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
 // Chunk pairs of d2q9_deep: a workgroup is two waves, the chunks 2p (down) and 2p+1 (up) of one strip (see deep_sweep).
 // units_per_band counts chunk PAIRS x strips.  LDS per wave: the four windows + the mailbox = 19.98 KB: four workgroups
 // (eight waves) still fit a CU.
-template <int D, bool NT, bool OBST_PATHS = false>
+template <int D, bool NT, bool OBST_PATHS = false, int LT = 0>
 __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, float *partials, int pstride, int nlev) {
   constexpr int WL = deep_lds_windows(D), HL = deep_halo_lanes(D);
   constexpr int kWaveFloats = WL * kPairWinFloats + (D - 1 > WL ? 3 * kPairSlotFloats : 0) + 4;
@@ -2057,9 +2057,9 @@ __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, floa
   const int xhalo_e = (xcol + 2 >= a.nx) ? 0 : xcol + 2;
   float *const mine = lds + wv * kWaveFloats, *const theirs = lds + (wv ^ 1) * kWaveFloats;
   if (wv != 0)  // odd chunks sweep up from their bottom row, even ones down from their top row: twins start together
-    deep_sweep<D, WL, true, NT, OBST_PATHS, true>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
+    deep_sweep<D, WL, true, NT, OBST_PATHS, true, LT>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
   else
-    deep_sweep<D, WL, false, NT, OBST_PATHS, true>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
+    deep_sweep<D, WL, false, NT, OBST_PATHS, true, LT>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
 }
 
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------

@@ -927,13 +927,16 @@ void launch_deep_twin(const lbm_ctx *c, const Slab &s, const Step2Args &a0, floa
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;
   if ((c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault) <= kDeepTwinDefault) {
     // all windows in LDS, no mailbox, 2 halo lanes per side
-    if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+    if (nt && paths && c->steady != 0 && nlev == kDeepTwinDefault) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, true, true, kDeepTwinDefault>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+    else if (!nt && paths && c->steady != 0 && nlev == kDeepTwinDefault) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, false, true, kDeepTwinDefault>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+    else if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
     else if (nt) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
     else if (paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
     else hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
     return;
   }
-  if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  if (nt && paths && c->steady != 0 && nlev == kDeepTwinSteps) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true, kDeepTwinSteps>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -1572,6 +1575,22 @@ int check_params(const lbm_params *p) {
 }
 
 // Allocate and fill one slab (rows [y0, y0+rows) of the global grid, plus halo rows in slab mode).
+// the slab's byte mask from the caller's int32[ny][nx] (d2q9-bgk.c:205-209: the obstacle transfer)
+int upload_mask(const lbm_ctx *c, Slab &s, const int32_t *obstacles) {
+  const int nx = c->p.nx, ny = c->p.ny;
+  const size_t n_ext = (size_t)nx * s.ext_rows;
+  // stored row e holds global row (y0 - row0 + e) mod ny: halo rows carry the neighbours' obstacle flags
+  std::vector<uint8_t> m(n_ext);
+  for (int e = 0; e < s.ext_rows; e++) {
+    const int gy = ((s.y0 - s.row0 + e) % ny + ny) % ny;
+    const int32_t *src = obstacles + (size_t)gy * nx;
+    for (int x = 0; x < nx; x++) m[(size_t)e * nx + x] = src[x] != 0;
+  }
+  if (set_dev(s)) return LBM_ERR_HIP;
+  HIP_TRY(hipMemcpy(s.mask, m.data(), n_ext, hipMemcpyHostToDevice));
+  return LBM_OK;
+}
+
 int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   const int nx = c->p.nx, ny = c->p.ny;
   const bool multi = c->halo_mode;
@@ -1607,16 +1626,7 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   }
   const size_t n_ext = (size_t)nx * s.ext_rows;
   if (dev_alloc(&s.mask, n_ext + 64)) return LBM_ERR_HIP;
-  {
-    // stored row e holds global row (y0 - row0 + e) mod ny: halo rows carry the neighbours' obstacle flags
-    std::vector<uint8_t> m(n_ext);
-    for (int e = 0; e < s.ext_rows; e++) {
-      const int gy = ((s.y0 - s.row0 + e) % ny + ny) % ny;
-      const int32_t *src = obstacles + (size_t)gy * nx;
-      for (int x = 0; x < nx; x++) m[(size_t)e * nx + x] = src[x] != 0;
-    }
-    HIP_TRY(hipMemcpy(s.mask, m.data(), n_ext, hipMemcpyHostToDevice));
-  }
+  if (int rc = upload_mask(c, s, obstacles)) return rc;
   // the accelerated row ny-2 (kernels.cl:18) in stored-row coordinates
   s.accel_own = s.accel_ext = s.accel_ext_b = -1;
   for (int e = 0; e < s.ext_rows; e++) {
@@ -2068,6 +2078,14 @@ int lbm_upload(lbm_ctx *c, const float *cells) {
   c->cur = 0;
   c->steps_done = 0;
   c->ring_fill = 0;
+  return LBM_OK;
+}
+
+int lbm_upload_obstacles(lbm_ctx *c, const int32_t *obstacles) {
+  if (!c || !obstacles) return fail(LBM_ERR_ARG, "NULL argument");
+  if (int rc = sync_all(c)) return rc;
+  for (Slab &s : c->slabs)
+    if (int rc = upload_mask(c, s, obstacles)) return rc;
   return LBM_OK;
 }
 

@@ -647,6 +647,34 @@ def test_dead_neighbour_costs_one_timeout(lbm):
         b.close()
 
 
+def test_obstacle_map_can_be_replaced(lbm, oracle_f32):
+    """lbm_upload_obstacles (the reference's clEnqueueWriteBuffer(obstacles), d2q9-bgk.c:205-209, as an entry point of its
+    own): a context whose map is replaced between runs continues exactly like a context created with the new map"""
+    rng = np.random.default_rng(5)
+    nx, ny, n = 256, 96, 12
+    ob_a, cells0 = random_case(rng, nx, ny)
+    ob_b = (rng.random((ny, nx)) < 0.08).astype(np.int32)
+    p = lbm.make_params(nx, ny, 2 * n, obstacles=ob_b)
+    p.free_cells_inv = np.float32(1.0)
+    with lbm.LBM(p, ob_a) as sim:
+        sim.upload(cells0)
+        sim.run(n)
+        mid, _ = sim.download()
+        sim.upload_obstacles(ob_b)
+        sim.run(n)
+        got, av = sim.download()
+    with lbm.LBM(p, ob_b) as sim:
+        sim.upload(mid)
+        sim.run(n)
+        ref, av_ref = sim.download()
+    assert np.array_equal(got, ref) and max_rel(av[n:], av_ref) < 2e-6
+    po = oracle_params(oracle_f32, p, ob_b)
+    po.free_cells_inv = np.float32(1.0)
+    orc = mid.copy()
+    oracle_f32.run(po, orc, ob_b, n)
+    assert max_rel(got, orc) < RTOL_CELLS
+
+
 def test_y_extension_invariance_16384x16384(lbm):
     """a grid whose arrays exceed 2^31 floats (16384x16384: 2.4e9 floats per grid): for fewer steps than rows the flow
     only knows the rows around the accelerated row ny-2, so the 96 rows around it — and the velocity sums — must equal
@@ -870,7 +898,7 @@ def test_three_steps_per_launch_equals_single_steps(lbm, nx, ny, chunk, nsteps, 
                                          (1024, 300, 128), (2048, 130, 0), (1000, 77, 9)])
 @pytest.mark.parametrize("nsteps", [2, 3, 6, 7, 8, 13, 20, 23])
 @pytest.mark.parametrize("depth,obst_paths,pair,nt", [(6, 0, 0, -1), (8, 1, 0, -1), (8, 0, 1, -1), (7, 1, 1, -1), (8, 1, -1, -1),
-                                                      (8, 1, 0, 1), (7, 1, 0, 1), (6, 1, 0, 1)])
+                                                      (8, 1, 0, 1), (7, 1, 0, 1), (6, 1, 0, 1), (8, 1, 1, 1), (8, 1, -1, 1)])
 def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, depth, obst_paths, pair, nt):
     """d2q9_deep (up to eight timesteps per launch; lanes of two cells, explicit packed collision, four LDS windows + up to
     three register windows, x-shifted planes read back from LDS already shifted; obst_paths = 1: a second collision path
