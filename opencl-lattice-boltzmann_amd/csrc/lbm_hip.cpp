@@ -355,9 +355,22 @@ bool deep_possible(const lbm_ctx *c) {
 // 768x768 107 / 122, 1024x768 127 / 138, 1024x1024 140 / 149-152, 1536x1024 168 / 190, 2048x1024 187 / 218, 2048x2048 219-226 /
 // 238-240, 3072x2048 250 / 264; against the lone kernel at eight steps: 8192x1024 265 / 261, 4096x4096 304 / 291, 8192x2048
 // 305 / 290 -> twins below 8M cells.  (Twins at three / four / five steps per launch: 1024x1024 130 / 146 / 149.)
+// Round 3, with the steady forms of both kernels (profiles/r03_twin_policy.txt; GLUPS lone at 8 / twins at 5 / twins at 8
+// steps per launch): 1024x1024 - / 177 / 133, 1536x1024 - / 206 / 170, 2048x1024 - / 227 / 194, 2048x2048 206 (four-step) /
+// 251 / 289, 3072x2048 292 / 274 / 320, 4096x2048 311 / 268 / 331, 3072x3072 319 / 257 / 337, 8192x1024 309 / 269 / 323,
+// 4096x4096 356 / 266 / 373, 6144x4096 369 / 265 / 364, 8192x4096 383 / 296 / 405, 8192x6144 410 / 304 / 415, 8192x8192
+// 422 / 279 / 431, 12288x8192 435 / 323 / 440 -> one slab without halo rows always runs chunk pairs: at up to five steps
+// per launch below 3M cells (the D = 5 instantiation: 60-lane strips, no register windows), at up to eight from 3M cells
+// (multi-round schedules included: the steady form made a pair's iterations cheap enough that holding the LDS of both
+// chunks no longer costs more than the halved start-up saves).
+constexpr long kTwinDeepCells = 3L << 20;
+int twin_cap(const lbm_ctx *c) {
+  if (c->twin_steps > 0) return c->twin_steps;
+  return (long)c->p.nx * c->rows_min >= kTwinDeepCells ? kDeepTwinSteps : kDeepTwinDefault;
+}
 bool deep_twin_effective(const lbm_ctx *c) {
   if (c->halo_mode || c->slabs.empty() || !c->slabs[0].f6_twin.paired) return false;
-  return c->pair > 0 || (long)c->p.nx * c->rows_min < (8L << 20);
+  return c->pair != 0;
 }
 // 0 = one launch per step, 2 = d2q9_step2, 3 = d2q9_step3 (falls back to 2 for the last steps of a run and
 // where the halo rows are fewer than 3)
@@ -545,7 +558,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
       // Twins of up to five steps per launch run the D = 5 instantiation: 2 halo lanes per side instead of 4, strips of up
       // to 60 lanes (starts on 32-byte boundaries: these grids live in the caches).  1024x1024: 9 strips instead of 10 (the
       // tenth held 8 useful lanes), 226 chunks of 4.5 rows instead of 172 of 6.
-      const int tw_cap = c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault;
+      const int tw_cap = twin_cap(c);
       if (tw_cap <= kDeepTwinDefault) {
         const int lmax5 = 64 - 2 * lbm::deep_halo_lanes(kDeepTwinDefault);
         s.strips_tw = div_up(q2, lmax5 / 4 * 4);
@@ -555,7 +568,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
         s.lanes_tw = s.lanes2;
       }
       if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_twin, 2, 0, true, s.strips_tw)) return rc;
-      s.f6_twin.paired = s.f6_twin.single_round || c->pair > 0;
+      s.f6_twin.paired = s.f6_twin.single_round || c->pair > 0 || (long)c->p.nx * c->rows_min >= kTwinDeepCells;
       if (s.f6_twin.paired) s.nb_total = std::max(s.nb_total, s.f6_twin.units);
     }
     return LBM_OK;
@@ -925,7 +938,7 @@ void launch_deep_twin(const lbm_ctx *c, const Slab &s, const Step2Args &a0, floa
   a.units_per_band = a0.units_per_band / 2;  // chunk pairs x strips
   const dim3 grid(s.f6_twin.units / 2), block(128);
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;
-  if ((c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault) <= kDeepTwinDefault) {
+  if (twin_cap(c) <= kDeepTwinDefault) {
     // all windows in LDS, no mailbox, 2 halo lanes per side
     if (nt && paths && c->steady != 0 && nlev == kDeepTwinDefault) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, true, true, kDeepTwinDefault>), grid, block, 0, st, a, partials, s.nb_total, nlev);
     else if (!nt && paths && c->steady != 0 && nlev == kDeepTwinDefault) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, false, true, kDeepTwinDefault>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -936,6 +949,8 @@ void launch_deep_twin(const lbm_ctx *c, const Slab &s, const Step2Args &a0, floa
     return;
   }
   if (nt && paths && c->steady != 0 && nlev == kDeepTwinSteps) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true, kDeepTwinSteps>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths && c->steady != 0 && nlev == 7) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true, 7>), grid, block, 0, st, a, partials, s.nb_total, nlev);
+  else if (nt && paths && c->steady != 0 && nlev == 6) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true, 6>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, false, true>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -1203,7 +1218,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       // the remaining steps in as few launches as possible, of equal depth (every launch moves the whole grid once:
       // 20 steps = 7+7+6, not 8+8+4)
       kind = KIND_DEEP;
-      const int cap = deep_twin ? std::min(fuse_lvl, c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault) : fuse_lvl;
+      const int cap = deep_twin ? std::min(fuse_lvl, twin_cap(c)) : fuse_lvl;
       adv = div_up(nsteps - i, div_up(nsteps - i, cap));
     } else if (fuse_lvl == 4 && nsteps - i >= 4) {
       kind = KIND_FUSED4;
@@ -2428,7 +2443,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "launch_steps")) {
     // most timesteps one launch (launch set) of the context's main kernel advances
     const int ms = multistep_effective(c), lvl = fuse_level(c);
-    *value = ms > 0 ? ms : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, c->twin_steps > 0 ? c->twin_steps : kDeepTwinDefault) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
+    *value = ms > 0 ? ms : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, twin_cap(c)) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
   }
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;

@@ -146,18 +146,18 @@ def test_lds_multistep_equals_single_steps(lbm, oracle_f32_omp, nx, ny, T, nstep
 
 def test_default_kernel_choice_by_grid_size(lbm):
     """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel in between, three- and four-step kernels
-    for bandwidth-bound ones, the deep window kernel from 560K cells — as chunk pairs with up to five steps per launch below 8M
-    cells, alone with up to eight above"""
+    for bandwidth-bound ones, the deep window kernel from 560K cells — as chunk pairs (d2q9_deep_twin), with up to five steps
+    per launch below 3M cells and up to eight from there on"""
     expect = {(128, 128): (8, 0, 8), (256, 256): (8, 0, 8), (512, 512): (8, 0, 8), (768, 512): (0, 1, 2), (1024, 512): (0, 3, 3),
-              (768, 768): (0, 8, 5), (1024, 1024): (0, 8, 5), (1536, 1024): (0, 8, 5), (2048, 2048): (0, 8, 5), (3072, 2048): (0, 8, 5),
-              (4096, 2048): (0, 8, 8), (8192, 1024): (0, 8, 8), (128, 8192): (0, 0, 1)}
+              (768, 768): (0, 8, 5), (1024, 1024): (0, 8, 5), (1536, 1024): (0, 8, 5), (2048, 1024): (0, 8, 5), (2048, 2048): (0, 8, 8),
+              (3072, 2048): (0, 8, 8), (4096, 2048): (0, 8, 8), (8192, 1024): (0, 8, 8), (128, 8192): (0, 0, 1)}
     for (nx, ny), (ms, fuse, per_launch) in expect.items():
         ob = np.zeros((ny, nx), np.int32)
         with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
             assert (sim.get_option("multistep"), sim.get_option("fuse") if not ms else 0) == (ms, fuse), (nx, ny)
             assert sim.get_option("launch_steps") == per_launch, (nx, ny)
-            if fuse == 8:   # the deep window kernel runs as chunk pairs (d2q9_deep_twin) exactly where a launch advances five steps
-                assert sim.get_option("pair") == (1 if per_launch == 5 else 0), (nx, ny)
+            if fuse == 8:   # one slab without halo rows: the deep window kernel always runs as chunk pairs (d2q9_deep_twin)
+                assert sim.get_option("pair") == 1, (nx, ny)
             sim.run(4)  # and it runs
 
 
@@ -600,6 +600,7 @@ def test_benchmarked_configuration_vs_oracle(lbm, oracle_f32_omp, nsteps, fuse):
         if fuse >= 0:
             sim.set_option("fuse", fuse)
         assert sim.get_option("fuse") == 8 and sim.get_option("launch_steps") == 8 and sim.get_option("multistep") == 0
+        assert sim.get_option("pair") == 1   # (the default on one slab: chunk pairs, d2q9_deep_twin)
         sim.upload(None)
         sim.run(nsteps)
         got, av = sim.download()
