@@ -4,9 +4,11 @@
 frequent kernel and `skip`-th..(skip+16)-th dispatches as (start, end) in microseconds relative to the first of them —
 where a launch set's time goes (kernel, gap, kernel, ...)."""
 import csv
+import signal
 import sys
 from collections import defaultdict
 
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)   # `| head` is fine
 rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else len(rows) // 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
