@@ -9,15 +9,19 @@ iv = {"interior": [], "edge": [], "xchg": []}
 for r in rows:
     name, st, en = r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0))
-    if "d2q9_step2" in name or "d2q9_step3" in name or "d2q9_step4" in name or "d2q9_multi" in name:
+    if "d2q9_step2" in name or "d2q9_step3" in name or "d2q9_step4" in name or "d2q9_multi" in name or "d2q9_deep" in name:
         iv["pending"] = iv.get("pending", []) + [(st, en, grid)]
     elif "nccl" in name.lower() or "rccl" in name.lower() or "halo_push" in name or "halo_wait" in name:
         iv["xchg"].append((st, en))
-# the edge launch has 3*strips units (a few thousand threads), the interior launches many more
+# the edge launch has 3*strips units (a few thousand threads), the interior launches many more; compact launch sets
+# (peer transport) are ONE launch per set — its first workgroups are the edge units, which push the halo rows while the
+# interior units of the same launch run: all launches have the same grid then and count as "interior"
 p = iv.pop("pending")
-gmin = min(g for _, _, g in p)
+gmin, gmax = min(g for _, _, g in p), max(g for _, _, g in p)
 for st, en, g in p:
-    (iv["edge"] if g <= 2 * gmin else iv["interior"]).append((st, en))
+    (iv["edge"] if (g <= 2 * gmin and gmax > 2 * gmin) else iv["interior"]).append((st, en))
+if not iv["edge"]:
+    print("compact launch sets: one launch per set, the edge units and their pushes are inside it (no separate edge / push kernels)")
 def overlap(a, others):
     tot = 0
     for (s, e) in others:
