@@ -219,9 +219,14 @@ class TransportFailed(RuntimeError):
 class Env:
     """what every leg needs: the library binding, torch.distributed and this rank's place in the job"""
 
-    def __init__(self, lbm_amd, torch, dist, rank, world, local_rank, device):
+    def __init__(self, lbm_amd, torch, dist, rank, world, local_rank, device, rehearsal=False):
         self.lbm, self.torch, self.dist = lbm_amd, torch, dist
         self.rank, self.world, self.local_rank, self.device = rank, world, local_rank, device
+        # rehearsal (LBM_BENCH_REHEARSAL=1): N ranks as N processes on fewer GPUs than ranks — torch.distributed over gloo,
+        # contexts without RCCL communicator (RCCL refuses two ranks per device), halo rows by peer stores over HIP IPC,
+        # velocity records added up here.  Exercises every N > 1 code path of this file on a one-GPU box; its numbers
+        # are NOT a benchmark (the ranks share a GPU) and the line says so.
+        self.rehearsal = rehearsal
 
     def all_ok(self, ok):
         """the ranks' vote: True only if every rank says so (an all-reduce, so it also lines the ranks up)"""
@@ -239,9 +244,12 @@ class RankSim:
 
     def __init__(self, env, params, obstacles, transport):
         lbm_amd, dist = env.lbm, env.dist
-        cid = share_comm_id(dist, env.rank, lbm_amd.comm_id() if env.rank == 0 else None,
-                            lbm_amd.load_library().lbm_comm_id_size(), env.device)
+        cid = None
+        if not env.rehearsal:
+            cid = share_comm_id(dist, env.rank, lbm_amd.comm_id() if env.rank == 0 else None,
+                                lbm_amd.load_library().lbm_comm_id_size(), env.device)
         self.sim = lbm_amd.LBM(params, obstacles, rank=env.rank, nranks=env.world, device=env.local_rank, comm=cid)
+        self.env = env
         self.transport = transport
         self.error = None
         if transport == "peer":
@@ -254,7 +262,8 @@ class RankSim:
             if all(any(b) for b in infos):          # the same answer on every rank
                 try:
                     self.sim.connect_peers(infos[(env.rank - 1) % env.world], infos[(env.rank + 1) % env.world])
-                    self.sim.set_option("transport", 3)   # (a context with a communicator stays on RCCL until told)
+                    if cid is not None:
+                        self.sim.set_option("transport", 3)   # (a context with a communicator stays on RCCL until told)
                     self.sim.set_option("halo_timeout_ms", PEER_TIMEOUT_MS)
                 except lbm_amd.LBMError as e:
                     self.error = str(e)
@@ -264,6 +273,15 @@ class RankSim:
                 self.error = self.error or "another rank could not map its ring neighbours"
                 self.close()
                 raise TransportFailed("peer: " + self.error)
+
+    def av_vels(self):
+        """the global av_vels record on every rank (a collective: every rank calls it)"""
+        av = self.sim.download(cells=False)[1]
+        if self.env.rehearsal:   # no communicator: the library returned this rank's own sums, the caller adds the ranks'
+            t = self.env.torch.from_numpy(av.astype(np.float64))
+            self.env.dist.all_reduce(t)
+            av = t.numpy().astype(np.float32)
+        return av
 
     def close(self):
         if self.sim is not None:
@@ -328,7 +346,7 @@ def rank_leg(env, params, obstacles, transports, warmup, steps, fuse=-1, profile
             entry["row_range"] = sim.row_range()
             entry["options"] = {k: sim.get_option(k) for k in ("fuse", "pair", "launch_steps", "multistep", "halo_depth")}
             if want_av:
-                entry["av"] = sim.download(cells=False)[1]     # collective (RCCL all-reduce): every rank got here
+                entry["av"] = rs.av_vels()     # collective (RCCL all-reduce): every rank got here
             if profile:
                 per = max(entry["options"]["multistep"], entry["options"]["launch_steps"], 1)
                 entry["per_rank"] = profile_all_ranks(env, sim, 8 * per, dict(rows=entry["row_range"][1] - entry["row_range"][0]))
@@ -376,7 +394,8 @@ def transport_check(env, transports, nsteps=64):
             rs.sim.upload(cells0)
             rs.sim.run(nsteps)
             synced(env, rs.sim)
-            got, av = rs.sim.download()
+            got = rs.sim.download(av_vels=False)[0]
+            av = rs.av_vels()
             y0, y1 = rs.sim.row_range()
             ec, ea = max_rel(got[:, y0:y1], ref[:, y0:y1]), max_rel(av, av_ref)
             ec, ea = max_over_ranks(env.dist, [ec, ea], env.device)
@@ -566,10 +585,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     visible = torch.cuda.device_count()
-    if max(world, args.gpus) > visible:
+    rehearsal = os.environ.get("LBM_BENCH_REHEARSAL") == "1"
+    if max(world, args.gpus) > visible and not rehearsal:
         if rank == 0:
             print("bench.py: %d GPUs needed, %d visible" % (max(world, args.gpus), visible), file=sys.stderr, flush=True)
         raise SystemExit(2)
+    local_rank = local_rank % visible     # (only a rehearsal has more ranks than devices)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # A single rank started by the launcher (LBM_BENCH_CHILD, or LBM_BENCH_RANK_MODE=1 by hand) drives the
@@ -578,8 +599,11 @@ def main():
     rank_mode = world > 1 or os.environ.get("LBM_BENCH_RANK_MODE") == "1" or (launched and os.environ.get("LBM_BENCH_CHILD") == "1")
     if rank_mode and world == 1:
         lbm_amd.set_default("force_halo", 1)
-    dist = init_dist("nccl", rank, world, device) if rank_mode else None
-    env = Env(lbm_amd, torch, dist, rank, world, local_rank, device)
+    if rehearsal and not rank_mode and not one_process:
+        raise SystemExit("LBM_BENCH_REHEARSAL=1 needs ranks or slabs: --gpus N with N > 1, or --launcher torchrun")
+    dist = init_dist("gloo" if rehearsal else "nccl", rank, world, device) if rank_mode else None
+    coll_device = torch.device("cpu") if rehearsal else device   # where the collectives' tensors live
+    env = Env(lbm_amd, torch, dist, rank, world, local_rank, coll_device, rehearsal)
     version = lbm_amd.load_library().lbm_version().decode()
 
     nx = args.nx
@@ -591,7 +615,7 @@ def main():
 
     def plain_leg(p, ob, warmup, steps, fuse=-1, want_av=False, before=None):
         """one context in this process (one slab, or --launcher one-process: one slab per device)"""
-        with (lbm_amd.LBM(p, ob, devices=list(range(ndev))) if ndev > 1 else lbm_amd.LBM(p, ob)) as sim:
+        with (lbm_amd.LBM(p, ob, devices=[i % visible for i in range(ndev)]) if ndev > 1 else lbm_amd.LBM(p, ob)) as sim:
             if fuse >= 0:
                 sim.set_option("fuse", fuse)
             sim.upload(None)
@@ -615,7 +639,8 @@ def main():
     cold = None
     if not args.no_cold:
         if rank_mode:
-            c = rank_leg(env, params, obstacles, ["rccl"], args.warmup, args.steps, args.fuse, profile=False)["rccl"]
+            c = list(rank_leg(env, params, obstacles, ["peer" if rehearsal else "rccl"], args.warmup, args.steps, args.fuse,
+                              profile=False).values())[0]
         else:
             c = plain_leg(params, obstacles, args.warmup, args.steps, args.fuse)
         if "wall_s" in c:
@@ -648,7 +673,7 @@ def main():
     # ---- N ranks: every transport against the oracle first; only those that pass are timed ---------------------------
     tcheck, transports = None, [None]
     if rank_mode:
-        want = {"both": ["rccl", "peer"], "peer": ["peer"], "rccl": ["rccl"]}[args.transport]
+        want = ["peer"] if rehearsal else {"both": ["rccl", "peer"], "peer": ["peer"], "rccl": ["rccl"]}[args.transport]
         tcheck = transport_check(env, want)
         transports = [t for t in want if tcheck["transports"][t]["ok"]]
 
@@ -709,7 +734,10 @@ def main():
                                  for k, v in runs.items()}
             out["transport"] = best
             out["transport_check"] = tcheck
-            out["rccl_world_size"] = world
+            out["rccl_world_size"] = 0 if rehearsal else world
+            if rehearsal:
+                out["rehearsal"] = ("LBM_BENCH_REHEARSAL=1: %d ranks as processes on %d GPU(s), gloo rendezvous, no RCCL communicator, peer "
+                                    "stores over HIP IPC — a test of the N > 1 code path, NOT a benchmark" % (world, visible))
         if b.get("per_rank"):
             out["per_rank_launch_set_us"] = b["per_rank"]
 

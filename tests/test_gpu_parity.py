@@ -782,6 +782,54 @@ def test_bench_starts_its_own_ranks():
     assert j["weak"]["per_gpu"] == j["weak"]["value"] and len(j["weak"]["per_rank_launch_set_us"]) == 1
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_bench_rehearsal_of_the_multi_rank_path(nranks):
+    """every N > 1 code path of bench.py on the one GPU of this box: `python bench.py --gpus N` (LBM_BENCH_REHEARSAL=1) starts N
+    ranks itself; the ranks are real processes that own row slabs of ONE grid, rendezvous over gloo, map their ring
+    neighbours through HIP IPC and move halo rows by peer stores (RCCL refuses two ranks per device, so the rehearsal
+    runs without communicator and adds the velocity records up itself).  Checked: the transport against the oracle
+    (transport_check), the timed record against the oracle (result_check), the per-rank launch-set gather, the
+    1024x1024 strong leg and the weak leg — with 3 ranks also uneven slabs (1024 = 342 + 341 + 341 rows)."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LBM_BENCH_RANK_MODE", "LBM_BENCH_CHILD")}
+    env["LBM_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "24", "--warmup", "8",
+                        "--nx", "2048", "--ny", "1024", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == nranks and j["result_ok"] is True and "NOT a benchmark" in j["rehearsal"]
+    assert j["config"]["partition"] == "rows x%d" % nranks and abs(j["config"]["rows_per_gpu"] - 1024 / nranks) < 1
+    assert set(j["transports"]) == {"peer"} and j["transport"] == "peer" and j["rccl_world_size"] == 0
+    tc = j["transport_check"]["transports"]["peer"]
+    assert tc["ok"] and tc["cells_max_rel"] < 2e-5 and tc["av_vels_max_rel"] < 1e-4
+    assert j["result_check"]["compared_steps"] >= 3 and j["result_check"]["av_vels_max_rel_vs_oracle"] < 1e-4
+    pr = j["per_rank_launch_set_us"]
+    assert [p["rank"] for p in pr] == list(range(nranks)) and all(p["transport"] == "peer" and p["sets"] >= 1 for p in pr)
+    assert sum(p["rows"] for p in pr) == 1024
+    assert j["also"]["value"] > 100 and len(j["also"]["per_rank_launch_set_us"]) == nranks
+    assert j["weak"]["scaling"] == "weak" and j["weak"]["workload"].startswith("2048x%d" % (1024 * nranks)) and j["weak"]["value"] > 100
+    assert j["value_cold"] > 100
+
+
+def test_bench_one_process_form_rehearsal():
+    """--launcher one-process: ONE process drives N row slabs (lbm_create(ndev = N)) — the form
+    bench.py falls back to where torch.distributed.run is missing; rehearsed with 4 slabs on the one GPU"""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LBM_BENCH_RANK_MODE", "LBM_BENCH_CHILD")}
+    env["LBM_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launcher", "one-process", "--steps", "24",
+                        "--warmup", "8", "--nx", "2048", "--ny", "1024", "--no-cpu-baseline", "--no-extra"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 4 and j["result_ok"] is True and j["launcher"].startswith("one process, lbm_create(ndev=4)")
+    assert j["config"]["rows_per_gpu"] == 256 and j["per_rank_launch_set_us"][0]["sets"] >= 1
+
+
 def test_bench_one_process_per_gpu_path_single_rank():
     """the driver's multi-GPU launch line (torch.distributed.run, one rank per GPU, RCCL) with ONE rank that is its
     own ring neighbour: torch.distributed's nccl backend and the library's RCCL communicator (ncclCommInitRank from
