@@ -192,8 +192,12 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  at most that many timesteps per launch: a run is cut into the fewest launches, of equal depth
  *                  (20 steps = 7 + 7 + 6); with row slabs capped by the halo depth (8 for slabs of 5M cells and more);
  *                  falls back to 4 on grids under 32 rows per slab.  0 = one launch per step, -1 = auto (by size: 8
- *                  from 5M cells per slab; one slab without halo rows: from 560K cells, as chunk pairs below 8M).
- *   "twin_steps"   chunk-pair form of the deep window kernel ("pair"): most timesteps per launch, 2..8, 0 = auto (5)
+ *                  from 5M cells per slab; one slab without halo rows: from 560K cells, always as chunk pairs).
+ *   "twin_steps"   chunk-pair form of the deep window kernel ("pair"): most timesteps per launch, 2..8, 0 = auto (5 below
+ *                  3M cells, 8 from there on)
+ *   "steady"       deep window kernel: -1/1 = a launch of exactly 5 (chunk pairs below 3M cells), 6, 7 or 8 timesteps runs the
+ *                  kernel instantiated for that depth (general form of the row loop while the levels start up, then a steady
+ *                  form whose level chain is straight-line code), 0 = the any-depth kernel always.  Same results bit for bit.
  *   "edge_aware"   deep window kernel with row slabs: -1/1 = one-round interior schedule whose last units take over the
  *                  wave slots of the edge launch, 0 = slots reserved for the whole launch set
  *   "obst_paths"   deep window kernel: 1 (and -1, auto) = waves that hold no blocked cell take a collision path without
@@ -205,7 +209,7 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "pair"         chunk-pair form of the three- / four-step kernels and of the deep window kernel (two chunks that start
  *                  at a common boundary run as one workgroup and hand each other their first rows instead of computing
  *                  them twice): 1 = always, 0 = never, -1 = auto (where all units of a launch are resident at once; the
- *                  deep window kernel: below 8M cells, one slab without halo rows)
+ *                  deep window kernel: one slab without halo rows)
  *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
  *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)
