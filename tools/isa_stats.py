@@ -4,7 +4,8 @@
 Without a file it compiles csrc/lbm_hip.cpp to assembly first (hipcc -S --cuda-device-only, ~15 s).  For every
 kernel whose mangled name contains one of the filters (default: the default template instances of the multi-step
 kernels) it prints registers / LDS / spills from the metadata and the instruction classes of (a) the whole kernel
-and (b) its hottest loop = the backward branch that spans the most instructions (the steady row loop).
+and (b) its loops — the blocks the compiler's comments assign to each loop header — ordered by arithmetic content: the row
+loops of the two sweep directions, in their general (start-up) and steady forms.
 Used for the VALU-diet bookkeeping in DESIGN.md (v_cndmask / v_mov per loop body)."""
 import os
 import re
@@ -62,25 +63,34 @@ def kernels(text):
         yield cur, body
 
 
-def hottest_loop(body):
-    """instructions between a label and the backward branch to it that spans the most instructions"""
-    labels, ins = {}, []
+def loops(body):
+    """(all instructions, {loop header label: [instructions of the blocks the compiler marks as part of that loop]}) — from the
+    block comments of the assembly ('=>This Inner Loop Header', 'in Loop: Header=BBn_m'): blocks of a loop need not be
+    contiguous in the layout, so a label-to-backward-branch span would miss or mix them"""
+    ins, per, cur = [], {}, None
     for ln in body:
-        m = re.match(r"^(\.LBB\w+):", ln)
+        m = re.match(r"^\.(LBB\w+):\s*(;.*)?$", ln)
         if m:
-            labels[m.group(1)] = len(ins)
+            c = m.group(2) or ""
+            if "Loop Header" in c:
+                cur = m.group(1)
+            else:
+                h = re.search(r"in Loop: Header=(BB\w+)", c)
+                cur = "L" + h.group(1) if h else None
+            continue
+        h = re.match(r"^; %bb\.\d+:\s*;\s*in Loop: Header=(BB\w+)", ln)
+        if h:
+            cur = "L" + h.group(1)
+            continue
+        if re.match(r"^; %bb\.\d+:", ln):
+            cur = None
             continue
         s = ln.strip()
         if ln.startswith("\t") and s and not s.startswith((".", ";")):
             ins.append(s)
-    best = (0, 0, 0)
-    for i, s in enumerate(ins):
-        m = re.match(r"s_cbranch\w*\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)", s)
-        if m:
-            tgt = m.group(1) or m.group(2)
-            if tgt in labels and labels[tgt] <= i and i - labels[tgt] > best[0]:
-                best = (i - labels[tgt], labels[tgt], i)
-    return ins, ins[best[1]:best[2] + 1]
+            if cur:
+                per.setdefault(cur, []).append(s)
+    return ins, per
 
 
 def main():
@@ -101,13 +111,15 @@ def main():
     for name, body in kernels(text):
         if not any(f in name for f in filters):
             continue
-        ins, loop = hottest_loop(body)
+        ins, per = loops(body)
         v, sp, lds, sg = meta.get(name, (0, 0, 0, 0))
         print("%s\n  vgpr %d  spilled %d  lds %d B  sgpr %d" % (name, v, sp, lds, sg))
-        for label, seq in (("kernel", ins), ("hottest loop", loop)):
-            c = Counter(classify(s.split()[0]) for s in seq)
+        # the kernel, then its loops by arithmetic content (the row loops of the two sweep directions, general and steady form)
+        rows = [("kernel", ins)] + [("loop " + h, seq) for h, seq in sorted(per.items(), key=lambda kv: -sum(1 for x in kv[1] if x.startswith("v_pk")))[:4]]
+        for label, seq in rows:
+            c = Counter(classify(x.split()[0]) for x in seq)
             valu = sum(n for k, n in c.items() if k.startswith("v_") or k == "dpp")
-            print("  %-12s %5d instructions, VALU %5d: " % (label, len(seq), valu) +
+            print("  %-14s %5d instructions, VALU %5d: " % (label, len(seq), valu) +
                   "  ".join("%s %d" % (k, c[k]) for k in ("v_pk", "v_other", "v_trans", "v_cndmask", "v_mov", "dpp", "lds", "vmem", "salu", "s_waitcnt", "other") if c[k]))
 
 
