@@ -29,6 +29,9 @@ for (nx, ny, nsteps) in ((1024, 1024, 23), (2048, 512, 19), (512, 300, 37), (409
     cases.append((nx, ny, nsteps, ob, cells0, p, ref, av_ref))
 variants = [dict(fuse=8, pair=0), dict(fuse=8, pair=1, twin_steps=5), dict(fuse=8, pair=1, twin_steps=8), dict(fuse=7, pair=1, twin_steps=7),
             dict(fuse=6, pair=1, twin_steps=6), dict(fuse=8, pair=1, twin_steps=3), dict(fuse=8, pair=0, slabs=2), dict(fuse=8, pair=0, slabs=4)]
+# round 3: with non-temporal stores (what the big grids run) launches of exactly 5 / 6 / 7 / 8 timesteps take the kernels
+# instantiated per depth (steady form of the row loop); every variant once more in that configuration
+variants += [dict(v, nt_stores=1) for v in variants]
 t0, runs, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     for (nx, ny, nsteps, ob, cells0, p, ref, av_ref) in cases:
