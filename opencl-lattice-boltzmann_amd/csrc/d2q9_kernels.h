@@ -1563,7 +1563,9 @@ __global__ __launch_bounds__(128, 2) void d2q9_step4p(const Step2Args a, float *
 //  - planes that move along x are read back from the LDS window already shifted by one cell (an unaligned 8-byte read
 //    at +-4 bytes: ds_read2_b32) instead of DPP + moves; a wave runs ONE sweep direction as a template parameter, so
 //    the plane roles are fixed at compile time (no selects) — per cell and step 64 VALU instructions instead of 92;
-//  - the depth is a launch argument (nlev <= D): a run is cut into the fewest launches, of equal depth;
+//  - the depth is a launch argument (nlev <= D): a run is cut into the fewest launches, of equal depth; for the depths runs
+//    are actually cut into (6, 7, 8; the twins' 5) there is a kernel instantiated per depth (template value LT) whose row
+//    loop switches, once all levels are running, to a STEADY form with a straight-line level chain (see deep_sweep);
 //  - the last level's row is stored one iteration late, right before that iteration's loads (see deep_sweep);
 //  - what is known about a row (is it the accelerated row, is it one of the chunk's own rows) is computed once, for
 //    level 0, and travels to the deeper levels in scalar shift registers: level l works on the row level 0 had l
@@ -1908,8 +1910,6 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L_arg, 
     }
     if (!STEADY && TWIN && twinned && k <= L - 2) __syncthreads();  // both twins run these iterations; the hand-over of iteration k is read in k+1
   };
-  // start-up in the general form (level l joins in iteration sf*l), then — for the depths whole runs are cut into — the
-  // steady form to the end of the chunk; other depths (the shallow launches at the end of a run) stay general
   // Start-up in the general form (level l joins in iteration sf*l), then the steady form to the end of the chunk.  The
   // steady form exists in kernels instantiated for ONE depth (LT > 0: the launch advances exactly LT timesteps, L is
   // that constant); LT = 0 is the kernel for any depth, general form throughout.  (Tried and dropped: all depths in one
