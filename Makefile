@@ -53,8 +53,14 @@ $(EXE)-asan: $(PKG)/host/d2q9-bgk.c tests/cpu/lbm_stub.c include/lbm.h
 oracle-asan:
 	$(MAKE) -C oracle asan
 
+# stand-alone measurement programs (not part of the product): tools/barrier_probe (grid barriers against launch boundaries,
+# profiles/r03_persistent_kernel_negative.txt), tools/deep_probe (the harness the deep window kernel was built in)
+probes: tools/barrier_probe tools/deep_probe
+tools/%: tools/%.cpp
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -I/opt/rocm/include $< -o $@
+
 clean:
 	rm -f $(LIB) $(EXE) $(EXE).exe $(EXE)-asan
 	$(MAKE) -C oracle clean
 
-.PHONY: all check clean oracle asan oracle-asan
+.PHONY: all check clean oracle asan oracle-asan probes
