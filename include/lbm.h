@@ -103,7 +103,7 @@ int lbm_connect_peers(lbm_ctx *ctx, const void *south_info, const void *north_in
  * Process-wide defaults for contexts created afterwards (validated; replace the environment hooks of round 1):
  *   "force_halo"  0 | 1   a single slab also carries halo rows and exchanges them with itself (a ring of one): the
  *                         whole multi-GPU machinery of a rank on one GPU (tests, tools/scaling_projection.py)
- *   "halo_depth"  0 = by slab size (8 small slabs and slabs from 5M cells / 4 from 2M cells / 3 / 2 thin slabs), else 2..8
+ *   "halo_depth"  0 = by slab size (8 small slabs and slabs from 3M cells / 4 from 2M cells / 3 / 2 thin slabs), else 2..8
  *   "transport"   0 = auto, 1 = RCCL send/recv, 2 = device-to-device copies, 3 = peer stores
  *   "lanes_out"   0 = auto (60), else 4..62: output lanes per 64-lane strip of the window kernels
  */
@@ -190,9 +190,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  of the traffic), 4 = four timesteps per launch (with row slabs only where the halo rows are 4
  *                  deep — slabs of 2M cells and more — else 3), 6..8 = the deep window kernel (lanes of two cells) with
  *                  at most that many timesteps per launch: a run is cut into the fewest launches, of equal depth
- *                  (20 steps = 7 + 7 + 6); with row slabs capped by the halo depth (8 for slabs of 5M cells and more);
+ *                  (20 steps = 7 + 7 + 6); with row slabs capped by the halo depth (8 for slabs of 3M cells and more);
  *                  falls back to 4 on grids under 32 rows per slab.  0 = one launch per step, -1 = auto (by size: 8
- *                  from 5M cells per slab; one slab without halo rows: from 560K cells, always as chunk pairs).
+ *                  from 3M cells per slab; one slab without halo rows: above 300K cells, always as chunk pairs).
  *   "twin_steps"   chunk-pair form of the deep window kernel ("pair"): most timesteps per launch, 2..8, 0 = auto (5 below
  *                  3M cells, 8 from there on)
  *   "steady"       deep window kernel: -1/1 = a launch of exactly 5 (chunk pairs below 3M cells), 6, 7 or 8 timesteps runs the

@@ -364,6 +364,11 @@ bool deep_possible(const lbm_ctx *c) {
 // (multi-round schedules included: the steady form made a pair's iterations cheap enough that holding the LDS of both
 // chunks no longer costs more than the halved start-up saves).
 constexpr long kTwinDeepCells = 3L << 20;
+// Row slabs run the deep window kernel (8 halo rows, launch sets of up to eight steps) from this many cells per slab, the
+// four-step kernel (4 halo rows) below.  Round 3, ring of one over peer stores, GLUPS four-step / deep (profiles/
+// r03_scaling_projection.txt): 2048x1024 and 4096x512 (2M cells) 176 / 161 and 172 / 167; 2048x2048, 4096x1024, 8192x512
+// (4M) 209 / 244, 210 / 245, 201 / 238 -> from 3M cells (round 2, before the per-depth kernels: 5M).
+constexpr long kSlabDeepCells = 3L << 20;
 int twin_cap(const lbm_ctx *c) {
   if (c->twin_steps > 0) return c->twin_steps;
   return (long)c->p.nx * c->rows_min >= kTwinDeepCells ? kDeepTwinSteps : kDeepTwinDefault;
@@ -395,8 +400,11 @@ int fuse_level(const lbm_ctx *c) {
     // as long as the four-step kernel's launch —, 5: 1007, 6: 1113, 7: 1304, 8: 1455 us = 369 GLUPS)
     // (with the band count of a one-round schedule chosen freely, r02: 2048x2048 220 / 222, 3072x2048 232 / 252, 4096x2048
     // 251 / 268, 3072x3072 242 / 272, 4096x4096 270 / 323, 8192x1024 256 / 277, 8192x2048 275 / 317, 8192x8192 293 / 367)
-    // ... and, as chunk pairs, from 560K cells (see deep_twin_effective)
-    if (deep_possible(c) && (cells >= 5L << 20 || (cells >= 560L * 1024 && deep_twin_effective(c)))) lvl = kDeepSteps;
+    // ... and, as chunk pairs, from 300K cells — right above the LDS tile kernel's range (see deep_twin_effective; round 3,
+    // GLUPS two- / three-step kernel against the pairs with their steady form at five steps per launch,
+    // profiles/r03_twin_policy.txt: 512x512 67.6 (LDS tiles) / 66.7, 640x512 75.6 / 83.4, 768x512 87.6 / 94.2, 768x640 93.1 /
+    // 109.1, 1024x512 97.4 / 101.9; round 2's threshold was 560K cells)
+    if (deep_possible(c) && (cells >= kSlabDeepCells || (cells > 300L * 1024 && deep_twin_effective(c)))) lvl = kDeepSteps;
   }
   if (lvl > 4 && !(lvl >= kDeepMin && lvl <= kDeepSteps && deep_possible(c))) lvl = 4;
   if (lvl >= kDeepMin && c->halo_mode) lvl = std::min(lvl, c->halo_depth);
@@ -1949,7 +1957,7 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     const bool big = (long)params->nx * rows_min >= (2L << 20);
     c->halo_depth = (small && rows_min >= 2 * kMultiMaxT) ? kMultiMaxT : (big ? 4 : (rows_min >= 6 ? 3 : 2));
     // ... and slabs of 5M cells and more depth 8 again: d2q9_deep, up to eight steps per launch set
-    if ((long)params->nx * rows_min >= (5L << 20) && rows_min >= 4 * kDeepSteps && params->nx % 4 == 0 && params->nx >= 256)
+    if ((long)params->nx * rows_min >= kSlabDeepCells && rows_min >= 4 * kDeepSteps && params->nx % 4 == 0 && params->nx >= 256)
       c->halo_depth = kDeepSteps;
     if (g_defaults.halo_depth > 0) c->halo_depth = g_defaults.halo_depth;
     if (rows_min < 2 * c->halo_depth) c->halo_depth = 2;

@@ -146,9 +146,10 @@ def test_lds_multistep_equals_single_steps(lbm, oracle_f32_omp, nx, ny, T, nstep
 
 def test_default_kernel_choice_by_grid_size(lbm):
     """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel in between, three- and four-step kernels
-    for bandwidth-bound ones, the deep window kernel from 560K cells — as chunk pairs (d2q9_deep_twin), with up to five steps
-    per launch below 3M cells and up to eight from there on"""
-    expect = {(128, 128): (8, 0, 8), (256, 256): (8, 0, 8), (512, 512): (8, 0, 8), (768, 512): (0, 1, 2), (1024, 512): (0, 3, 3),
+    for bandwidth-bound ones, the deep window kernel above 300K cells — as chunk pairs (d2q9_deep_twin), with up to five steps
+    per launch below 3M cells and up to eight from there on; grids of fewer than 32 rows, which the deep kernel does not take, fall
+    back to the two- / three-step kernels"""
+    expect = {(128, 128): (8, 0, 8), (256, 256): (8, 0, 8), (512, 512): (8, 0, 8), (640, 512): (0, 8, 5), (768, 512): (0, 8, 5), (1024, 512): (0, 8, 5), (16384, 24): (0, 1, 2), (32768, 24): (0, 3, 3),
               (768, 768): (0, 8, 5), (1024, 1024): (0, 8, 5), (1536, 1024): (0, 8, 5), (2048, 1024): (0, 8, 5), (2048, 2048): (0, 8, 8),
               (3072, 2048): (0, 8, 8), (4096, 2048): (0, 8, 8), (8192, 1024): (0, 8, 8), (128, 8192): (0, 0, 1)}
     for (nx, ny), (ms, fuse, per_launch) in expect.items():
@@ -360,7 +361,7 @@ def test_row_slabs_four_steps_per_launch(lbm, nslabs, ny, halo_defaults):
 
 @pytest.mark.parametrize("nslabs,nx,ny,depth", [(2, 256, 64, 8), (3, 512, 130, 8), (2, 1024, 260, 6), (4, 260, 200, 7), (5, 256, 160, 8)])
 def test_row_slabs_deep_kernel(lbm, nslabs, nx, ny, depth, halo_defaults):
-    """slabs with halo depth 8 (what slabs of 5M cells and more get) and d2q9_deep on edge + interior launches: bit-identical
+    """slabs with halo depth 8 (what slabs of 3M cells and more get) and d2q9_deep on edge + interior launches: bit-identical
     to one slab; 37 steps = launch sets of 8, 8, 7, 7, 7 (depth 8); a halo depth below the kernel's limit caps the sets"""
     halo_defaults(halo_depth=8 if depth != 7 else 7)
     rng = np.random.default_rng(60 + nslabs)
