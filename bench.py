@@ -353,6 +353,7 @@ def rank_leg(env, params, obstacles, transports, warmup, steps, fuse=-1, profile
                 synced(env, sim)
         except TransportFailed as e:
             entry = {"error": str(e)[:300]}
+            print("bench.py: rank %d: transport %s failed on a %dx%d grid: %s" % (env.rank, tr, params.nx, params.ny, str(e)[:300]), file=sys.stderr, flush=True)
         finally:
             if rs is not None:
                 rs.close()
@@ -403,6 +404,7 @@ def transport_check(env, transports, nsteps=64):
                    "halo_depth": rs.sim.get_option("halo_depth")}
         except TransportFailed as e:
             res = {"ok": False, "error": str(e)[:300]}
+            print("bench.py: rank %d: transport %s failed the oracle check: %s" % (env.rank, tr, str(e)[:300]), file=sys.stderr, flush=True)
         finally:
             if rs is not None:
                 rs.close()
@@ -856,7 +858,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
         if not ok:
-            print("bench.py: result_ok is false: %s" % json.dumps((out or {}).get("result_check") or (out or {}).get("error")), file=sys.stderr, flush=True)
+            print("bench.py: result_ok is false: %s" % json.dumps({k: (out or {}).get(k) for k in ("result_check", "error", "transports", "transport_check")}),
+                  file=sys.stderr, flush=True)
     if dist is not None:
         # the line is out; a rendezvous backend that objects to the order in which the ranks hang up must not turn a good
         # record into a failed run
