@@ -1767,9 +1767,22 @@ int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *whi
     l.flags = (uint32_t *)(uintptr_t)info.flags_ptr;
   } else {
     void *p0 = nullptr, *p1 = nullptr, *pf = nullptr;
-    hipError_t e = hipIpcOpenMemHandle(&p0, info.cells[0], hipIpcMemLazyEnablePeerAccess);
-    if (e == hipSuccess) e = hipIpcOpenMemHandle(&p1, info.cells[1], hipIpcMemLazyEnablePeerAccess);
-    if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf, info.flags, hipIpcMemLazyEnablePeerAccess);
+    // (a neighbour's grids are opened by BOTH its ring neighbours at about the same moment — right after the descriptors
+    // have been gathered; an open that fails is tried again a few times before the transport is given up)
+    auto open_retry = [](void **p, hipIpcMemHandle_t h) {
+      hipError_t e = hipSuccess;
+      for (int attempt = 0; attempt < 4; attempt++) {
+        e = hipIpcOpenMemHandle(p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+        *p = nullptr;
+        usleep(20000u << attempt);
+      }
+      return e;
+    };
+    hipError_t e = open_retry(&p0, info.cells[0]);
+    if (e == hipSuccess) e = open_retry(&p1, info.cells[1]);
+    if (e == hipSuccess) e = open_retry(&pf, info.flags);
     if (e != hipSuccess) {
       if (p0) hipIpcCloseMemHandle(p0);
       if (p1) hipIpcCloseMemHandle(p1);
