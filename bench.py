@@ -284,7 +284,16 @@ class RankSim:
         return av
 
     def close(self):
+        """Collective: every rank unmaps its neighbours' grids, the ranks meet, and only then does anybody free its own —
+        device memory that another process still has mapped through HIP IPC must not be freed (undefined behaviour; a first
+        version that closed rank by rank failed once in three full test-suite runs on some boxes)."""
         if self.sim is not None:
+            if self.transport == "peer":
+                try:
+                    self.sim.disconnect_peers()
+                except self.env.lbm.LBMError:
+                    pass
+                self.env.all_ok(True)
             self.sim.close()
             self.sim = None
 

@@ -98,6 +98,15 @@ int lbm_comm_get_id(void *comm_id_out);
 size_t lbm_peer_info_size(void);
 int lbm_peer_info(lbm_ctx *ctx, void *info_out);
 int lbm_connect_peers(lbm_ctx *ctx, const void *south_info, const void *north_info);
+/*
+ * Unmap the ring neighbours' grids and flag words (waits for this context's queued work first).  ORDER OF TEAR-DOWN
+ * between processes: every rank calls lbm_disconnect_peers, the caller synchronises the ranks (a barrier), and only then
+ * does any rank call lbm_destroy — freeing device memory that another process still has mapped through HIP IPC is
+ * undefined behaviour (as with CUDA IPC).  lbm_destroy alone is enough inside one process and for a rank whose
+ * neighbours have already gone.  Afterwards the context is back on RCCL send/recv if it has a communicator, else
+ * without transport until lbm_connect_peers is called again.
+ */
+int lbm_disconnect_peers(lbm_ctx *ctx);
 
 /*
  * Process-wide defaults for contexts created afterwards (validated; replace the environment hooks of round 1):

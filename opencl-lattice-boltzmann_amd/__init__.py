@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "lbm_run_timed", "lbm_sync", "lbm_download", "lbm_steps_done", "lbm_row_range", "lbm_final_state",
     "lbm_reynolds", "lbm_set_option", "lbm_get_option", "lbm_copy_bandwidth", "lbm_valu_rate", "lbm_destroy",
     "lbm_last_error", "lbm_version", "lbm_set_default", "lbm_peer_info_size", "lbm_peer_info", "lbm_connect_peers",
-    "lbm_run_profiled", "lbm_upload_obstacles",
+    "lbm_run_profiled", "lbm_upload_obstacles", "lbm_disconnect_peers",
 ]
 
 TRANSPORTS = {"auto": 0, "rccl": 1, "copy": 2, "peer": 3}
@@ -84,6 +84,7 @@ def load_library():
     L.lbm_peer_info_size.restype = ctypes.c_size_t
     L.lbm_peer_info.argtypes = [vp, vp]
     L.lbm_connect_peers.argtypes = [vp, vp, vp]
+    L.lbm_disconnect_peers.argtypes = [vp]
     L.lbm_destroy.argtypes = [vp]
     L.lbm_destroy.restype = None
     L.lbm_last_error.restype = cp
@@ -286,6 +287,11 @@ class LBM:
         so = ctypes.create_string_buffer(south_info, len(south_info))
         no = ctypes.create_string_buffer(north_info, len(north_info))
         _check(self.lib.lbm_connect_peers(self.ctx, so, no), "lbm_connect_peers")
+
+    def disconnect_peers(self):
+        """Unmap the neighbours' grids.  Between processes: every rank calls this, then a barrier, then close() — memory that
+        another process still has mapped must not be freed."""
+        _check(self.lib.lbm_disconnect_peers(self.ctx), "lbm_disconnect_peers")
 
     def set_option(self, key, value):
         _check(self.lib.lbm_set_option(self.ctx, key.encode(), int(value)), "lbm_set_option(%s)" % key)

@@ -1922,6 +1922,23 @@ int lbm_connect_peers(lbm_ctx *c, const void *south_info, const void *north_info
   return rebuild_geometry(c);
 }
 
+int lbm_disconnect_peers(lbm_ctx *c) {
+  if (!c) return fail(LBM_ERR_ARG, "ctx is NULL");
+  if (!c->halo_mode || c->slabs.size() != 1) return fail(LBM_ERR_STATE, "lbm_disconnect_peers is for rank contexts");
+  // let the work that is queued finish (an error word raised by a dead neighbour must not keep the mappings open)
+  for (Slab &s : c->slabs) {
+    hipSetDevice(s.dev);
+    if (s.s_edge) (void)hipStreamSynchronize(s.s_edge);
+    if (s.s_main) (void)hipStreamSynchronize(s.s_main);
+  }
+  (void)hipGetLastError();
+  Slab &s = c->slabs[0];
+  close_link(s.north);
+  close_link(s.south);
+  if (c->transport_eff == TRANSPORT_PEER) c->transport_eff = s.comm ? TRANSPORT_RCCL : TRANSPORT_AUTO;
+  return LBM_OK;
+}
+
 const char *lbm_last_error(void) { return g_err.c_str(); }
 #ifndef LBM_SRC_ID
 #define LBM_SRC_ID "unknown"

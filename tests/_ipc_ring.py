@@ -56,6 +56,8 @@ def main():
     avt = torch.from_numpy(av.astype(np.float64))
     dist.all_reduce(avt)
     dist.barrier()
+    sim.disconnect_peers()            # tear-down between processes: unmap, meet, and only then free (see lbm.h)
+    dist.barrier()
     sim.close()
     if rank == 0:
         with lbm_amd.LBM(p, ob) as one:

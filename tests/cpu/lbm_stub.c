@@ -53,6 +53,7 @@ int lbm_peer_info(lbm_ctx *c, void *o) { (void)c; memset(o, 0, 8); return LBM_OK
 int lbm_connect_peers(lbm_ctx *c, const void *a, const void *b) { (void)c; (void)a; (void)b; return LBM_OK; }
 int lbm_set_default(const char *k, long v) { (void)k; (void)v; return LBM_OK; }
 int lbm_upload(lbm_ctx *c, const float *cells) { (void)cells; c->steps = 0; return LBM_OK; }
+int lbm_disconnect_peers(lbm_ctx *c) { (void)c; return LBM_OK; }
 int lbm_upload_obstacles(lbm_ctx *c, const int32_t *obstacles) { (void)c; return obstacles ? LBM_OK : LBM_ERR_ARG; }
 int lbm_run(lbm_ctx *c, int n)
 {

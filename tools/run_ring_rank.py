@@ -57,6 +57,9 @@ def main():
               float(t[0]) / steps * 1e3, nx * ny * steps / float(t[0]) / 1e3, st["edge_us"], st["exchange_us"], st["interior_us"],
               st["set_period_us"]), flush=True)
     dist.barrier()
+    if transport != "rccl":
+        sim.disconnect_peers()        # unmap the neighbours' grids, meet, and only then free one's own
+        dist.barrier()
     sim.close()
     dist.destroy_process_group()
 
