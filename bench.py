@@ -297,6 +297,15 @@ class RankSim:
             self.sim.close()
             self.sim = None
 
+    def abandon(self):
+        """non-collective: this rank is leaving through an unexpected exception (the launcher will end the job); no vote —
+        the other ranks are not at the meeting point"""
+        if self.sim is not None:
+            try:
+                self.sim.close()
+            finally:
+                self.sim = None
+
 
 def synced(env, sim):
     """lbm_sync on every rank, then the vote: a transport that failed on one rank (LBM_ERR_COMM: a neighbour's halo
@@ -360,12 +369,15 @@ def rank_leg(env, params, obstacles, transports, warmup, steps, fuse=-1, profile
                 per = max(entry["options"]["multistep"], entry["options"]["launch_steps"], 1)
                 entry["per_rank"] = profile_all_ranks(env, sim, 8 * per, dict(rows=entry["row_range"][1] - entry["row_range"][0]))
                 synced(env, sim)
-        except TransportFailed as e:
+        except TransportFailed as e:   # raised on every rank alike (the ranks voted): the collective close below is safe
             entry = {"error": str(e)[:300]}
             print("bench.py: rank %d: transport %s failed on a %dx%d grid: %s" % (env.rank, tr, params.nx, params.ny, str(e)[:300]), file=sys.stderr, flush=True)
-        finally:
+        except BaseException:
             if rs is not None:
-                rs.close()
+                rs.abandon()
+            raise
+        if rs is not None:
+            rs.close()
         runs[tr] = entry
     return runs
 
@@ -414,9 +426,12 @@ def transport_check(env, transports, nsteps=64):
         except TransportFailed as e:
             res = {"ok": False, "error": str(e)[:300]}
             print("bench.py: rank %d: transport %s failed the oracle check: %s" % (env.rank, tr, str(e)[:300]), file=sys.stderr, flush=True)
-        finally:
+        except BaseException:
             if rs is not None:
-                rs.close()
+                rs.abandon()
+            raise
+        if rs is not None:
+            rs.close()
         out[tr] = res
     return {"workload": "input_1024x1024 obstacles, seeded random state, %d timesteps, rows x%d, vs the fp32 oracle "
                         "(cells <= 2e-5, av_vels <= 1e-4 relative)" % (nsteps, env.world), "transports": out}
