@@ -2026,25 +2026,47 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
 // Chunk pairs of d2q9_deep: a workgroup is two waves, the chunks 2p (down) and 2p+1 (up) of one strip (see deep_sweep).
 // units_per_band counts chunk PAIRS x strips.  LDS per wave: the four windows + the mailbox = 19.98 KB: four workgroups
 // (eight waves) still fit a CU.
-template <int D, bool NT, bool OBST_PATHS = false, int LT = 0>
+// PUSH: the compact launch-set form for a slab that exchanges halo rows (as d2q9_deep<..., PUSH>): the first edge_units / 2
+// workgroups are the EDGE workgroups — wave 0 works on the bottom edge rows, wave 1 on the top edge rows of one strip (chunks 0
+// and 2 of the edge table {bottom edge, (interior), top edge}); neither has a twin, both run alone, push their rows into
+// the ring neighbours, and the last edge wave raises the flag words —, the others are the interior's chunk pairs.
+template <int D, bool NT, bool OBST_PATHS = false, int LT = 0, bool PUSH = false>
 __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, float *partials, int pstride, int nlev) {
   constexpr int WL = deep_lds_windows(D), HL = deep_halo_lanes(D);
   constexpr int kWaveFloats = WL * kPairWinFloats + (D - 1 > WL ? 3 * kPairSlotFloats : 0) + 4;
   __shared__ float lds[2 * kWaveFloats];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int band = blockIdx.x % a.nbands, slot = blockIdx.x / a.nbands;
-  if (slot >= a.units_per_band) return;
-  const int punit = band * a.units_per_band + slot;
+  const UnitSel us = select_unit<PUSH>(a, a.edge_units / 2);
+  const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
+  if constexpr (PUSH) {
+    // in-kernel wait for the neighbours' halo rows (halo_sync = 2): every edge wave for itself, before its first load
+    if (us.edge && (a.peer_mode & 2)) {
+      const Step2Args *la = late_args<Step2Args>();
+      const HaloPeer *pp = la->peer;
+      if (lane < 2) spin_on_flag(pp->wait_flags + lane, la->wait_seq, pp->wait_err, pp->wait_ticks);
+    }
+  }
+  const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
+  if (slot >= us.units_per_band) return;  // units_per_band counts workgroups: chunk PAIRS x strips (edge: strips)
+  const int punit = band * us.units_per_band + slot;
   const int pair = punit / a.strips, strip = punit - pair * a.strips;
-  const int chunk = 2 * pair + wv;
-  const int unit = chunk * a.strips + strip;
-  const int ys = a.chunk_start[chunk], ye = a.chunk_start[chunk + 1];
-  const int pys = a.chunk_start[chunk ^ 1], pye = a.chunk_start[(chunk ^ 1) + 1];
-  const bool empty = ys >= ye || chunk == a.skip_chunk;
-  const bool twinned = !empty && pys < pye && (chunk ^ 1) != a.skip_chunk;  // the same on both waves
+  const int chunk = (PUSH && us.edge) ? 2 * wv : 2 * pair + wv;
+  const int unit = chunk * a.strips + strip + us.partial_off;
+  const int ys = us.chunk_start[chunk], ye = us.chunk_start[chunk + 1];
+  const int pys = us.chunk_start[chunk ^ 1], pye = us.chunk_start[(chunk ^ 1) + 1];
+  const bool empty = ys >= ye || (!(PUSH && us.edge) && chunk == us.skip);
+  const bool twinned = !(PUSH && us.edge) && !empty && pys < pye && (chunk ^ 1) != us.skip;  // the same on both waves
+  if constexpr (PUSH) {
+    // nobody works on the edge table's middle chunk (the interior): its slot of the velocity sums is this wave's to clear
+    if (us.edge && wv == 0 && lane < nlev) partials[(size_t)lane * pstride + (a.strips + strip + us.partial_off)] = 0.f;
+  }
   if (empty) {
     if (lane < nlev) partials[(size_t)lane * pstride + unit] = 0.f;
+    if constexpr (PUSH) {
+      const Step2Args *la = late_args<Step2Args>();
+      if (us.edge && (la->peer_mode & 1)) publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
     return;  // the twin then runs alone and meets no barrier
   }
   const int q2 = a.nx >> 1;
@@ -2060,6 +2082,13 @@ __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, floa
     deep_sweep<D, WL, true, NT, OBST_PATHS, true, LT>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
   else
     deep_sweep<D, WL, false, NT, OBST_PATHS, true, LT>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
+  if constexpr (PUSH) {
+    const Step2Args *la = late_args<Step2Args>();
+    if (do_push) {
+      push_chunk_pairs(la, ys, ye, xcol, owner);
+      publish_wave_when_last(la->peer, (unsigned)la->edge_units, la->seq);
+    }
+  }
 }
 
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------

@@ -604,8 +604,46 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     // n_full chunks of R rows for the slots that are free at once and, as the LAST units of the launch, two shorter
     // chunks of R - (edge iterations) rows: they are dispatched when the edge units retire and finish with the others.
     const int slots = s.cus * 4 * 2, edge_work = 2 * s.strips2, late_per_strip = 2;
-    const int n_full = (slots - edge_work) / s.strips2;
     const int rows = i1 - i0, delay = s.edge_rows + 2 * (kDeepSteps - 1);
+    // Chunk PAIRS for the interior (d2q9_deep_twin<..., PUSH>, compact launch sets only): a strip's edge rows are one
+    // workgroup (wave 0: bottom edge, wave 1: top edge, both running alone for edge_rows + 2(D-1) iterations), the interior
+    // n_pairs workgroups of two chunks of R rows that start at their common boundary (R + D-1 iterations) and, as the last
+    // workgroups of the launch, one late pair of R - delay rows that takes over the edge workgroup's slot.
+    s.f6_main.paired = false;
+    if (c->pair != 0 && c->edge_aware != 0 && compact_sets(c)) {
+      const int n_pairs = (slots - edge_work) / (2 * s.strips2);
+      const int Rp = n_pairs > 0 ? div_up(rows + 2 * delay, 2 * n_pairs + 2) : 0;
+      const int rp_late = Rp - delay;
+      if (n_pairs >= 1 && Rp <= c6max && rp_late >= 4) {
+        std::vector<int> starts;
+        int y = i0, left = rows;
+        const int nch = 2 * n_pairs + 2;
+        for (int k = 0; k < nch; k++) {
+          const int remaining_full = std::max(0, 2 * n_pairs - k);
+          int sz = k < 2 * n_pairs ? div_up(std::max(0, left - 2 * rp_late), std::max(1, remaining_full)) : std::min(rp_late, left);
+          if (k == nch - 1) sz = left;
+          sz = std::max(0, std::min(sz, left));
+          starts.push_back(y);
+          y += sz;
+          left -= sz;
+        }
+        starts.push_back(i1);
+        FuseGeom &g = s.f6_main;
+        g.nbands = 1;
+        g.nchunks = nch;
+        g.units_per_band = g.nchunks * s.strips2;
+        g.units = g.units_per_band;
+        g.single_round = true;
+        g.paired = true;
+        if (g.chunk_start) HIP_TRY(hipFree(g.chunk_start));
+        g.chunk_start = nullptr;
+        if (dev_alloc(&g.chunk_start, starts.size())) return LBM_ERR_HIP;
+        HIP_TRY(hipMemcpy(g.chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
+        s.nb_total = std::max(s.nb_total, s.f6_main.units + e.units);
+        return LBM_OK;
+      }
+    }
+    const int n_full = (slots - edge_work) / s.strips2;
     const int R = n_full > 0 ? div_up(rows + late_per_strip * delay, n_full + late_per_strip) : 0;
     const int r_late = R - delay;
     if (c->edge_aware != 0 && n_full >= 2 && R <= c6max && r_late >= 4) {
@@ -633,8 +671,12 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
       g.chunk_start = nullptr;
       if (dev_alloc(&g.chunk_start, starts.size())) return LBM_ERR_HIP;
       HIP_TRY(hipMemcpy(g.chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
-    } else if (int rc = fuse_schedule(s, i0, i1, c6max, c6min, true, s.f6_main, 2, 2 * edge_work, false, s.strips2)) {
-      return rc;
+    } else {
+      // more rows than one round of units takes (the slabs of a 2-GPU run, of the weak-scaling leg): the tapered multi-round
+      // schedule, as chunk pairs where the launch set is compact (measured on one slab without halo rows: 8192x4096 383 -> 405)
+      const bool pairs = c->pair != 0 && compact_sets(c) && rows > (long)c6max * n_full;
+      if (int rc = fuse_schedule(s, i0, i1, c6max, c6min, true, s.f6_main, 2, 2 * edge_work, pairs, s.strips2)) return rc;
+      s.f6_main.paired = pairs;
     }
   }
   s.nb_total = std::max(s.nb_total, s.f6_main.units + e.units);
@@ -928,8 +970,22 @@ void launch_deep_compact(const lbm_ctx *c, const Slab &s, const Step2Args &a0, f
   Step2Args a = a0;
   a.strips = s.strips2;
   a.lanes_out = s.lanes2;
-  const dim3 grid(a0.edge_units + s.f6_main.units), block(64);
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;
+  if (s.f6_main.paired) {
+    // interior chunk pairs + one edge workgroup per strip (bottom and top edge rows on its two waves): d2q9_deep_twin<..., PUSH>
+    a.units_per_band = a0.units_per_band / 2;     // chunk pairs x strips
+    a.edge_units = 2 * s.strips2;                 // edge WAVES (what the last of them counts up to); edge workgroups = half
+    const dim3 pgrid(s.strips2 + s.f6_main.units / 2), pblock(128);
+    if (nt && paths && c->steady != 0 && nlev == 8) hipLaunchKernelGGL((d2q9_deep_twin<kDeepSteps, true, true, 8, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    else if (nt && paths && c->steady != 0 && nlev == 7) hipLaunchKernelGGL((d2q9_deep_twin<kDeepSteps, true, true, 7, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    else if (nt && paths && c->steady != 0 && nlev == 6) hipLaunchKernelGGL((d2q9_deep_twin<kDeepSteps, true, true, 6, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    else if (nt && paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepSteps, true, true, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    else if (nt) hipLaunchKernelGGL((d2q9_deep_twin<kDeepSteps, true, false, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    else if (paths) hipLaunchKernelGGL((d2q9_deep_twin<kDeepSteps, false, true, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    else hipLaunchKernelGGL((d2q9_deep_twin<kDeepSteps, false, false, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    return;
+  }
+  const dim3 grid(a0.edge_units + s.f6_main.units), block(64);
   if (nt && paths && c->steady != 0 && nlev == 8) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true, 8>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt && paths && c->steady != 0 && nlev == 7) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true, 7>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt && paths && c->steady != 0 && nlev == 6) hipLaunchKernelGGL((d2q9_deep<kDeepSteps, true, true, true, 6>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -2476,7 +2532,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
-  else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? deep_twin_effective(c) : fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
+  else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? (c->halo_mode ? (compact_sets(c) && c->slabs[0].f6_main.paired) : deep_twin_effective(c)) : fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
   else if (!strcmp(key, "launch_steps")) {
     // most timesteps one launch (launch set) of the context's main kernel advances

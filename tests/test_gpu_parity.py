@@ -314,7 +314,10 @@ def test_transport_self_ring(transport):
 @pytest.mark.parametrize("world,nx,ny,nsteps,fuse,multistep,sync", [(2, 512, 96, 23, 3, 0, 0), (2, 512, 96, 23, 8, 0, 0), (4, 2048, 256, 30, 8, 0, 0), (3, 256, 150, 29, 0, 8, 0),
                                                                    (4, 2048, 64, 14, 4, 0, 1), (2, 256, 24, 11, 0, 0, 1),
                                                                    (4, 1024, 256, 203, 0, 8, 2), (2, 300, 40, 37, 0, 5, 2),
-                                                                   (4, 2048, 256, 30, 4, 0, 2), (3, 1024, 300, 25, 3, 0, 2)])
+                                                                   (4, 2048, 256, 30, 4, 0, 2), (3, 1024, 300, 25, 3, 0, 2),
+                                                                   # slabs of 704 / 1400 rows: the interior runs as chunk pairs (d2q9_deep_twin<..., PUSH>),
+                                                                   # one round with a late pair / the tapered multi-round schedule
+                                                                   (2, 8192, 1408, 23, 8, 0, 0), (3, 8192, 4200, 16, 8, 0, 2)])
 def test_peer_transport_between_processes(world, nx, ny, nsteps, fuse, multistep, sync):
     """the peer transport across PROCESS boundaries: `world` processes share the one GPU, each owns a row slab, maps
     its neighbours' grids and flag words through HIP IPC, pushes its edge rows into them and waits on its own flags
@@ -375,6 +378,32 @@ def test_row_slabs_deep_kernel(lbm, nslabs, nx, ny, depth, halo_defaults):
         sim.set_option("multistep", 0)
         sim.set_option("fuse", 8 if depth == 7 else depth)
         assert sim.get_option("fuse") == depth and sim.get_option("halo_depth") == (7 if depth == 7 else 8)
+        sim.upload(cells0)
+        sim.run(nsteps)
+        many, av_many = sim.download()
+    assert np.array_equal(one, many)
+    assert max_rel(av_many, av_one) < 2e-6
+
+
+@pytest.mark.parametrize("pair,halo_sync,nsteps", [(-1, 0, 23), (-1, 2, 16), (0, 0, 23)])
+def test_row_slabs_deep_kernel_chunk_pairs(lbm, pair, halo_sync, nsteps):
+    """row slabs big enough for the interior's chunk PAIRS (d2q9_deep_twin<..., PUSH>: one edge workgroup per strip — bottom
+    edge rows on wave 0, top edge rows on wave 1 — then the interior's pairs, a late pair last): 8192x1408 over two slabs of 704
+    rows (12 pairs + 1 late pair per strip), launch sets of 8 + 8 + 7 steps (per-depth kernels) or two of 8, peer stores with
+    the wait kernel or with the edge waves polling the flags themselves; bit-identical to single steps on one slab"""
+    rng = np.random.default_rng(77)
+    nx, ny = 8192, 1408
+    ob = (rng.random((ny, nx)) < 0.01).astype(np.int32)
+    ob[300:500, :] = 0           # a band without blocked cells: both collision paths
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
+    cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob, devices=[0, 0]) as sim:
+        sim.set_option("pair", pair)
+        sim.set_option("halo_sync", halo_sync)
+        assert sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8 and sim.get_option("transport") == 3
+        assert sim.get_option("pair") == (1 if pair != 0 else 0)
         sim.upload(cells0)
         sim.run(nsteps)
         many, av_many = sim.download()
