@@ -610,6 +610,8 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     // n_pairs workgroups of two chunks of R rows that start at their common boundary (R + D-1 iterations) and, as the last
     // workgroups of the launch, one late pair of R - delay rows that takes over the edge workgroup's slot.
     s.f6_main.paired = false;
+    // (two-stream launch sets — RCCL, copies — keep the lone kernel: an interior launch of pairs next to the edge launch and the
+    // exchange kernel was measured at 200 against 292 GLUPS on the 8192x1024 ring of one: the 40-KB pair workgroups crowd them out)
     if (c->pair != 0 && c->edge_aware != 0 && compact_sets(c)) {
       const int n_pairs = (slots - edge_work) / (2 * s.strips2);
       const int Rp = n_pairs > 0 ? div_up(rows + 2 * delay, 2 * n_pairs + 2) : 0;

@@ -385,12 +385,15 @@ def test_row_slabs_deep_kernel(lbm, nslabs, nx, ny, depth, halo_defaults):
     assert max_rel(av_many, av_one) < 2e-6
 
 
-@pytest.mark.parametrize("pair,halo_sync,nsteps", [(-1, 0, 23), (-1, 2, 16), (0, 0, 23)])
-def test_row_slabs_deep_kernel_chunk_pairs(lbm, pair, halo_sync, nsteps):
+@pytest.mark.parametrize("pair,halo_sync,nsteps,transport", [(-1, 0, 23, "peer"), (-1, 2, 16, "peer"), (0, 0, 23, "peer"), (-1, 0, 23, "copy")])
+def test_row_slabs_deep_kernel_chunk_pairs(lbm, pair, halo_sync, nsteps, transport, halo_defaults):
     """row slabs big enough for the interior's chunk PAIRS (d2q9_deep_twin<..., PUSH>: one edge workgroup per strip — bottom
     edge rows on wave 0, top edge rows on wave 1 — then the interior's pairs, a late pair last): 8192x1408 over two slabs of 704
     rows (12 pairs + 1 late pair per strip), launch sets of 8 + 8 + 7 steps (per-depth kernels) or two of 8, peer stores with
-    the wait kernel or with the edge waves polling the flags themselves; bit-identical to single steps on one slab"""
+    the wait kernel or with the edge waves polling the flags themselves; with device-to-device copies (two-stream launch sets: an
+    edge launch beside the interior launch) the interior stays on the lone kernel — pairs there were measured at 200 against 292
+    GLUPS, their 40-KB workgroups crowd out the edge launch and the exchange; bit-identical to single steps on one slab"""
+    halo_defaults(transport=transport)
     rng = np.random.default_rng(77)
     nx, ny = 8192, 1408
     ob = (rng.random((ny, nx)) < 0.01).astype(np.int32)
@@ -402,8 +405,9 @@ def test_row_slabs_deep_kernel_chunk_pairs(lbm, pair, halo_sync, nsteps):
     with lbm.LBM(p, ob, devices=[0, 0]) as sim:
         sim.set_option("pair", pair)
         sim.set_option("halo_sync", halo_sync)
-        assert sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8 and sim.get_option("transport") == 3
-        assert sim.get_option("pair") == (1 if pair != 0 else 0)
+        assert sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8
+        assert sim.get_option("transport") == {"peer": 3, "copy": 2}[transport]
+        assert sim.get_option("pair") == (1 if (pair != 0 and transport == "peer") else 0)
         sim.upload(cells0)
         sim.run(nsteps)
         many, av_many = sim.download()
