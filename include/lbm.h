@@ -218,7 +218,8 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "pair"         chunk-pair form of the three- / four-step kernels and of the deep window kernel (two chunks that start
  *                  at a common boundary run as one workgroup and hand each other their first rows instead of computing
  *                  them twice): 1 = always, 0 = never, -1 = auto (where all units of a launch are resident at once; the
- *                  deep window kernel: one slab without halo rows)
+ *                  deep window kernel: one slab without halo rows; with row slabs the interior of a compact launch set —
+ *                  peer stores — from about 650 rows per slab at 8192 cells a row)
  *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
  *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)
