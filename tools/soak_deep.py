@@ -16,7 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(7)
 w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
 cases = []
-for (nx, ny, nsteps) in ((1024, 1024, 23), (2048, 512, 19), (512, 300, 37), (4096, 1024, 16)):
+for (nx, ny, nsteps) in ((1024, 1024, 23), (2048, 512, 19), (512, 300, 37), (4096, 1024, 16), (8192, 1408, 23)):  # (the last: slabs of 704 rows run chunk pairs)
     ob = (rng.random((ny, nx)) < 0.04).astype(np.int32)
     cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
     p = lbm_amd.make_params(nx, ny, nsteps, obstacles=ob)
