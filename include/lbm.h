@@ -211,6 +211,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  wave slots of the edge launch, 0 = slots reserved for the whole launch set
  *   "obst_paths"   deep window kernel: 1 (and -1, auto) = waves that hold no blocked cell take a collision path without
  *                  the bounce-back selects, 0 = one path
+ *   "free_sweeps"  deep window kernel at 6, 7, 8 timesteps per launch: 1 (and -1, auto) = a wave whose chunk of rows holds no
+ *                  blocked cell inside its strip (looked up in a map built from the obstacle map) sweeps it without any
+ *                  obstacle handling, 0 = every wave looks level by level ("obst_paths").  Same results bit for bit.
  *   "windows"      where the three-step kernel keeps its two windows: 1 = LDS (two waves per SIMD), 0 = registers
  *                  (one wave per SIMD), -1 = auto (1)
  *   "load_bufs"    row-sets of source loads the three-step kernel keeps in flight: 1 or 2, 0 = auto

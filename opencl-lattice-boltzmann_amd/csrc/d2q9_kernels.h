@@ -549,6 +549,11 @@ struct Step2Args {
   uint32_t seq, wait_seq;        // peer_mode bit 1 (option halo_sync = 2): the edge waves — the only readers of halo rows —
                                  // poll the slab's own flag words for wait_seq before their first load (bounded spin)
   int peer_mode, peer_buf;       // peer_buf: which of the neighbours' two grids the pushed rows go to
+  // d2q9_deep / d2q9_deep_twin at the depths that have a kernel of their own: bit (r & 63) of word clean_bits[strip*clean_words
+  // + (r >> 6)] is set when stored row r holds a blocked cell inside that strip's 64 lanes (strip_row_bits); a wave whose rows
+  // are all clear runs the sweep without obstacle handling (deep_sweep<..., FREE>).  nullptr: no map, every wave looks.
+  const unsigned long long *clean_bits;
+  int clean_words;
 };
 
 // Which work unit a workgroup has (compact launch sets: edge schedule first).  All wave-uniform.
@@ -1714,6 +1719,54 @@ constexpr int deep_halo_lanes(int D) { return D / 2; }           // ceil((D-1)/2
 constexpr bool deep_edge_loads(int D) { return 2 * deep_halo_lanes(D) < D; }
 constexpr int deep_lds_windows(int D) { return D - 1 < 4 ? D - 1 : 4; }  // 4 x 4.5 KB + 1 register window: two waves per SIMD
 
+// The rows level 0 of a sweep works on — rows lo .. hi-1 before wrapping, at most ny of them — hold no blocked cell within
+// the strip's lanes (wave-uniform; a handful of scalar loads per chunk).  The deeper levels work on the same rows later.
+__device__ __forceinline__ bool strip_rows_clean(const unsigned long long *bits, int words, int strip, int lo, int hi, int ny) {
+  if (bits == nullptr || hi - lo >= ny) return false;
+  const unsigned long long *w = bits + (size_t)strip * words;
+  unsigned long long any = 0;
+  auto range = [&](int r0, int r1) {  // 0 <= r0 < r1 <= ny
+    for (int i = r0 >> 6; i <= (r1 - 1) >> 6; i++) {
+      const int b0 = r0 - 64 * i > 0 ? r0 - 64 * i : 0, b1 = r1 - 64 * i < 64 ? r1 - 64 * i : 64;
+      const unsigned long long upto = b1 == 64 ? ~0ull : ((1ull << b1) - 1ull);
+      any |= w[i] & upto & ~((1ull << b0) - 1ull);
+    }
+  };
+  int l0 = lo % ny;
+  if (l0 < 0) l0 += ny;
+  const int l1 = l0 + (hi - lo);
+  if (l1 <= ny) range(l0, l1);
+  else { range(l0, ny); range(0, l1 - ny); }
+  return __builtin_amdgcn_readfirstlane((int)(any == 0ull)) != 0;
+}
+// Level 0 of a sweep over the chunk [ys, ye) works on these rows (see deep_sweep: r0 + k*d for k = 0 .. last)
+__device__ __forceinline__ void deep_sweep_rows(bool up, bool twinned, int L, int ys, int ye, int *lo, int *hi) {
+  const int lead = twinned ? 0 : L - 1, count = (ye - ys) + lead + (L - 1);
+  const int first = up ? ys - lead : ye - 1 + lead - (count - 1);
+  *lo = first;
+  *hi = first + count;
+}
+
+// The map strip_rows_clean reads: one wave per (strip, word of 64 rows); a lane looks at the mask bytes of its own two
+// cells, exactly as issue_pair_loads / deep_sweep address them (lanes beyond the grid's last column wrap).
+__global__ __launch_bounds__(64) void strip_row_bits(const uint8_t *mask, int nx, int rows, int strips, int lanes_out, int halo_lanes,
+                                                     unsigned long long *bits, int words) {
+  const int strip = blockIdx.x % strips, word = blockIdx.x / strips, lane = threadIdx.x;
+  if (word >= words) return;
+  const int q2 = nx >> 1;
+  int qw = (strip * lanes_out + lane - halo_lanes) % q2;
+  if (qw < 0) qw += q2;
+  const int xcol = qw * 2;
+  unsigned long long out = 0;
+  for (int b = 0; b < 64; b++) {
+    const int r = word * 64 + b;
+    if (r >= rows) break;
+    const uint32_t m = *reinterpret_cast<const uint32_t *>(mask + (size_t)r * nx + (xcol & ~3)) >> ((xcol & 2) * 8);
+    if (__builtin_amdgcn_ballot_w64((m & 0xffffu) != 0) != 0ull) out |= 1ull << b;
+  }
+  if (lane == 0) bits[(size_t)strip * words + word] = out;
+}
+
 // TWIN (d2q9_deep_twin): the wave is one of the two of a workgroup that work on the chunks 2p (sweeping down) and 2p+1
 // (sweeping up) of one strip and START at their common boundary together — the chunk pairs of section 3.5.  A lone wave
 // primes its windows with L-1 rows beyond the start of its chunk, which are exactly its neighbour's first rows; twins
@@ -1723,7 +1776,12 @@ constexpr int deep_lds_windows(int D) { return D - 1 < 4 ? D - 1 : 4; }  // 4 x 
 // Levels whose window lives in registers receive the twin's row through a MAILBOX of three slots behind the wave's
 // windows: written in iteration l-1, read in iteration l (early: with the window reads of the level before), and a
 // barrier at the start of level l keeps the twin's next write (level l+1, later in the same iteration) behind that read.
-template <int D, int WL, bool UP, bool NT, bool OBST_PATHS, bool TWIN = false, int LT = 0>
+// FREE: the caller knows (strip_rows_clean) that none of the rows this sweep works on holds a blocked cell within the
+// strip — the whole sweep, start-up included, is the obstacle-free collision: no mask loads, no mask shift chain, no
+// ballot and branch per level, and no join of two collision paths for the register allocator to reconcile (the mixed
+// steady loop executes 782 VALU instructions per row on its obstacle-free path, this one 709).  Same arithmetic: a wave
+// without blocked cells takes collide2<false> either way.
+template <int D, int WL, bool UP, bool NT, bool OBST_PATHS, bool TWIN = false, int LT = 0, bool FREE = false>
 __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L_arg, float *lds, float *partials, int pstride, int ys, int ye,
                                            int xcol, int xhalo_w, int xhalo_e, int lane, bool owner, int unit,
                                            const bool twinned_in = false, float *lds_twin = nullptr) {
@@ -1827,9 +1885,9 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L_arg, 
         g[1] = pair_from_west(in.c[1]); g[5] = pair_from_west(in.c[5]); g[8] = pair_from_west(in.c[8]);
         g[3] = pair_from_east(in.c[3]); g[6] = pair_from_east(in.c[6]); g[7] = pair_from_east(in.c[7]);
       }
-      m_top = in.m >> mask_shift;  // (bits 16.. may hold the neighbouring pair's bytes: every test masks)
+      m_top = FREE ? 0u : in.m >> mask_shift;  // (bits 16.. may hold the neighbouring pair's bytes: every test masks)
       v2f t;
-      if (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_top & 0xffffu) != 0) == 0ull) t = collide2<false>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
+      if (FREE || (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_top & 0xffffu) != 0) == 0ull)) t = collide2<false>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
       else t = collide2<true>(g, m_top, a.omega, (accbits & 1u) != 0, a.aw1, a.aw2, top);
       if ((ownbits & 1u) && owner) sum[0] += t.x + t.y;
       // The row the last level finished in the PREVIOUS iteration is stored here, right before this iteration's loads:
@@ -1866,10 +1924,10 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L_arg, 
           g[4] = q[3]; g[8] = q[4]; g[7] = q[5];
           g[2] = top[2]; g[5] = pair_from_west(top[5]); g[6] = pair_from_east(top[6]);
         }
-        m_nxt = m_mid[l - 1];
+        m_nxt = FREE ? 0u : m_mid[l - 1];
         const bool acc = ((accbits >> l) & 1u) != 0;
         v2f t;
-        if (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_nxt & 0xffffu) != 0) == 0ull) t = collide2<false>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
+        if (FREE || (OBST_PATHS && __builtin_amdgcn_ballot_w64((m_nxt & 0xffffu) != 0) == 0ull)) t = collide2<false>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
         else t = collide2<true>(g, m_nxt, a.omega, acc, a.aw1, a.aw2, nxt);
         if (!final) {
           if (((ownbits >> l) & 1u) && owner) sum[l] += t.x + t.y;
@@ -1891,7 +1949,7 @@ __device__ __forceinline__ void deep_sweep(const Step2Args &a, const int L_arg, 
         for (int i = 0; i < 3; i++) R.S0[i] = R.S1[i];
         R.S1[0] = UP ? top[2] : top[4]; R.S1[1] = UP ? top[5] : top[8]; R.S1[2] = UP ? top[6] : top[7];
       }
-      m_mid[l - 1] = m_top;
+      if (!FREE) m_mid[l - 1] = m_top;
       if (!STEADY && TWIN && twinned && k == l - 1) {
         // `top` is the first row of level l-1: its planes that move the twin's way become the trail row of the twin's
         // first gather of level l, next iteration (the twin reads parity l & 1 then; its own puts reach that slot later;
@@ -2010,10 +2068,23 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
   const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
   const int xhalo_e = (xcol + 2 >= a.nx) ? 0 : xcol + 2;
   // even chunks sweep up, odd chunks down: neighbouring chunks meet at their common boundary rows at about the same time
-  if (__builtin_amdgcn_readfirstlane((int)((chunk & 1) == 0)))
+  const bool up = __builtin_amdgcn_readfirstlane((int)((chunk & 1) == 0)) != 0;
+  bool clean = false;
+  if constexpr (LT > 0 && OBST_PATHS) {  // (the kernels of the default configuration)
+    int lo, hi;
+    deep_sweep_rows(up, false, LT, ys, ye, &lo, &hi);
+    clean = strip_rows_clean(a.clean_bits, a.clean_words, strip, lo, hi, a.ny);
+  }
+  if (clean) {
+    if constexpr (LT > 0 && OBST_PATHS) {
+      if (up) deep_sweep<D, WL, true, NT, OBST_PATHS, false, LT, true>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+      else deep_sweep<D, WL, false, NT, OBST_PATHS, false, LT, true>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+    }
+  } else if (up) {
     deep_sweep<D, WL, true, NT, OBST_PATHS, false, LT>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
-  else
+  } else {
     deep_sweep<D, WL, false, NT, OBST_PATHS, false, LT>(a, nlev, lds, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit);
+  }
   if constexpr (PUSH) {
     const Step2Args *la = late_args<Step2Args>();
     if (do_push) {
@@ -2078,10 +2149,24 @@ __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, floa
   const int xhalo_w = (xcol == 0) ? a.nx - 1 : xcol - 1;
   const int xhalo_e = (xcol + 2 >= a.nx) ? 0 : xcol + 2;
   float *const mine = lds + wv * kWaveFloats, *const theirs = lds + (wv ^ 1) * kWaveFloats;
-  if (wv != 0)  // odd chunks sweep up from their bottom row, even ones down from their top row: twins start together
+  // odd chunks sweep up from their bottom row, even ones down from their top row: twins start together.  Each wave picks
+  // its own form of the sweep (both forms meet the same barriers)
+  bool clean = false;
+  if constexpr (LT > 0 && OBST_PATHS && D == 8) {
+    int lo, hi;
+    deep_sweep_rows(wv != 0, twinned, LT, ys, ye, &lo, &hi);
+    clean = strip_rows_clean(a.clean_bits, a.clean_words, strip, lo, hi, a.ny);
+  }
+  if (clean) {
+    if constexpr (LT > 0 && OBST_PATHS && D == 8) {
+      if (wv != 0) deep_sweep<D, WL, true, NT, OBST_PATHS, true, LT, true>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
+      else deep_sweep<D, WL, false, NT, OBST_PATHS, true, LT, true>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
+    }
+  } else if (wv != 0) {
     deep_sweep<D, WL, true, NT, OBST_PATHS, true, LT>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
-  else
+  } else {
     deep_sweep<D, WL, false, NT, OBST_PATHS, true, LT>(a, nlev, mine, partials, pstride, ys, ye, xcol, xhalo_w, xhalo_e, lane, owner, unit, twinned, theirs);
+  }
   if constexpr (PUSH) {
     const Step2Args *la = late_args<Step2Args>();
     if (do_push) {

@@ -216,6 +216,9 @@ struct Slab {
   FuseGeom f6_twin;               // one slab: pair schedule of d2q9_deep_twin (used where it is one round of units)
   int strips2 = 0, lanes2 = 0;    // x decomposition of d2q9_deep: strips per row, output lanes (of two cells) per strip
   int strips_tw = 0, lanes_tw = 0;  // ... of d2q9_deep_twin: at up to five steps per launch two halo lanes per side are enough
+  unsigned long long *clean_bits = nullptr;  // d2q9_deep's strips x stored rows: which hold a blocked cell (lbm::strip_row_bits)
+  int clean_words = 0;            // 64-row words per strip of that map
+  bool all_clean = false;         // no blocked cell anywhere in the slab's stored rows
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
   int m_tx = 32, m_ty = 16;          // its tile size (chosen by how many tiles the slab gives)
@@ -282,6 +285,8 @@ struct lbm_ctx {
   int steady = -1;          // d2q9_deep: 1 (and -1, auto) = launches of 6, 7 or 8 timesteps run the kernel instantiated for that depth (steady
                             // form of the row loop), 0 = the any-depth kernel always
   int obst_paths = -1;      // d2q9_deep: 1 (and -1, auto) = a second collision path without bounce-back selects for waves without blocked cells
+  int free_sweeps = -1;     // d2q9_deep at the depths with a kernel of their own: 1 (and -1, auto) = a wave whose rows hold no blocked cell in its
+                            // strip runs the sweep without obstacle handling (the map of Slab::clean_bits), 0 = every wave looks level by level
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
   int chunk_min = 0;        // shortest chunk at the tapered end of a band (0 = auto)
@@ -543,6 +548,39 @@ int fuse_schedule_pairs(const lbm_ctx *c, const Slab &s, int r0, int r1, int cma
     }
   }
   return fuse_schedule(s, r0, r1, cmax, cmin, true, g, waves_per_simd, reserve, false);
+}
+
+// Which stored rows hold a blocked cell within which strip of d2q9_deep (Step2Args::clean_bits): rebuilt whenever the strips
+// or the obstacle map change.  One pass over the byte mask on the device.
+int build_clean_bits(const lbm_ctx *c, Slab &s) {
+  if (s.strips2 <= 0 || !s.mask) return LBM_OK;
+  if (set_dev(s)) return LBM_ERR_HIP;
+  const int words = div_up(s.ext_rows, 64);
+  if (s.clean_bits) HIP_TRY(hipFree(s.clean_bits));
+  s.clean_bits = nullptr;
+  s.clean_words = words;
+  if (dev_alloc(&s.clean_bits, (size_t)s.strips2 * words)) return LBM_ERR_HIP;
+  hipLaunchKernelGGL(lbm::strip_row_bits, dim3(s.strips2 * words), dim3(64), 0, s.s_main, s.mask, c->p.nx, s.ext_rows, s.strips2, s.lanes2,
+                     lbm::deep_halo_lanes(kDeepSteps), s.clean_bits, words);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s.s_main));
+  std::vector<unsigned long long> host((size_t)s.strips2 * words);
+  HIP_TRY(hipMemcpy(host.data(), s.clean_bits, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  unsigned long long any = 0;
+  for (unsigned long long w : host) any |= w;
+  s.all_clean = any == 0;
+  return LBM_OK;
+}
+
+// Free sweeps by default (same-box A/B on an MI355X, GLUPS with / without, profiles/r03_free_sweeps.txt): where a launch is
+// several rounds of units — 8192x8192 cavity 463 / 446 — or nothing in the slab is blocked — no obstacles at all: 8192x8192
+// 476 / 456, 4096x4096 410 / 397, the 8192x1024 slab of an 8-GPU run 344 / 327.  A ONE-round launch that has blocked cells ends
+// with its slowest waves, the ones that look (the two wall strips of a cavity): the free waves' saving buys nothing there and
+// the second set of loops costs instruction-cache room — 4096x4096 cavity 376 / 375, 8192x1024 slab 319 / 325, 8192x2048 361 / 368.
+const unsigned long long *clean_bits_for(const lbm_ctx *c, const Slab &s, const FuseGeom &g) {
+  if (c->free_sweeps == 0 || !s.clean_bits) return nullptr;
+  if (c->free_sweeps < 0 && g.single_round && !s.all_clean) return nullptr;
+  return s.clean_bits;
 }
 
 // Schedules of d2q9_deep for a slab: lanes of two cells, deep_halo_lanes() of them idle at either end of a strip; strips
@@ -811,6 +849,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       s.nb_total = std::max(s.nb_total, s.f4_main.units);
     }
     if (int rc = deep_geometry(c, s)) return rc;
+    if (int rc = build_clean_bits(c, s)) return rc;
   }
   return LBM_OK;
 }
@@ -954,6 +993,8 @@ void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, int units
   Step2Args a = a0;
   a.strips = s.strips2;
   a.lanes_out = s.lanes2;
+  a.clean_bits = clean_bits_for(c, s, s.f6_main);
+  a.clean_words = s.clean_words;
   const dim3 grid(units), block(64);
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;  // (-1 auto = on)
   // the depths whole runs are cut into have a kernel of their own (steady form of the row loop, see deep_sweep); the
@@ -972,6 +1013,8 @@ void launch_deep_compact(const lbm_ctx *c, const Slab &s, const Step2Args &a0, f
   Step2Args a = a0;
   a.strips = s.strips2;
   a.lanes_out = s.lanes2;
+  a.clean_bits = clean_bits_for(c, s, s.f6_main);
+  a.clean_words = s.clean_words;
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;
   if (s.f6_main.paired) {
     // interior chunk pairs + one edge workgroup per strip (bottom and top edge rows on its two waves): d2q9_deep_twin<..., PUSH>
@@ -1014,6 +1057,8 @@ void launch_deep_twin(const lbm_ctx *c, const Slab &s, const Step2Args &a0, floa
     else hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinDefault, false, false>), grid, block, 0, st, a, partials, s.nb_total, nlev);
     return;
   }
+  a.clean_bits = clean_bits_for(c, s, s.f6_twin);  // (eight-step twins run d2q9_deep's strips: strips_tw == strips2)
+  a.clean_words = s.clean_words;
   if (nt && paths && c->steady != 0 && nlev == kDeepTwinSteps) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true, kDeepTwinSteps>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt && paths && c->steady != 0 && nlev == 7) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true, 7>), grid, block, 0, st, a, partials, s.nb_total, nlev);
   else if (nt && paths && c->steady != 0 && nlev == 6) hipLaunchKernelGGL((d2q9_deep_twin<kDeepTwinSteps, true, true, 6>), grid, block, 0, st, a, partials, s.nb_total, nlev);
@@ -1619,6 +1664,7 @@ void free_slab(Slab &s) {
     if (s.ev_edgek[i]) hipEventDestroy(s.ev_edgek[i]);
   }
   if (s.mask) hipFree(s.mask);
+  if (s.clean_bits) hipFree(s.clean_bits);
   if (s.partials) hipFree(s.partials);
   if (s.av_sum) hipFree(s.av_sum);
   if (s.fin_partials) hipFree(s.fin_partials);
@@ -2195,8 +2241,10 @@ int lbm_upload(lbm_ctx *c, const float *cells) {
 int lbm_upload_obstacles(lbm_ctx *c, const int32_t *obstacles) {
   if (!c || !obstacles) return fail(LBM_ERR_ARG, "NULL argument");
   if (int rc = sync_all(c)) return rc;
-  for (Slab &s : c->slabs)
+  for (Slab &s : c->slabs) {
     if (int rc = upload_mask(c, s, obstacles)) return rc;
+    if (int rc = build_clean_bits(c, s)) return rc;
+  }
   return LBM_OK;
 }
 
@@ -2435,6 +2483,11 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     c->obst_paths = (int)value;
     return LBM_OK;
   }
+  if (!strcmp(key, "free_sweeps")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "free_sweeps must be -1 (auto), 0 or 1");
+    c->free_sweeps = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "tile_shape")) {
     if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "tile_shape must be -1..2");
     if (int rc = sync_all(c)) return rc;
@@ -2544,6 +2597,14 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "steady")) *value = c->steady != 0;
+  else if (!strcmp(key, "free_sweeps")) {
+    // are the launches of the context's deep window kernel given the map?
+    *value = 0;
+    if (!c->slabs.empty() && fuse_level(c) >= kDeepMin) {
+      const Slab &s0 = c->slabs[0];
+      *value = clean_bits_for(c, s0, (!c->halo_mode && deep_twin_effective(c)) ? s0.f6_twin : s0.f6_main) != nullptr;
+    }
+  }
   else if (!strcmp(key, "halo_sync")) *value = c->halo_sync;
   else if (!strcmp(key, "halo_timeout_ms")) *value = (long)c->halo_timeout_ms;
   else if (!strcmp(key, "compact")) *value = compact_sets(c);

@@ -635,6 +635,7 @@ def test_benchmarked_configuration_vs_oracle(lbm, oracle_f32_omp, nsteps, fuse):
             sim.set_option("fuse", fuse)
         assert sim.get_option("fuse") == 8 and sim.get_option("launch_steps") == 8 and sim.get_option("multistep") == 0
         assert sim.get_option("pair") == 1   # (the default on one slab: chunk pairs, d2q9_deep_twin)
+        assert sim.get_option("free_sweeps") == 1   # (several rounds of units: waves away from the walls sweep without obstacle handling)
         sim.upload(None)
         sim.run(nsteps)
         got, av = sim.download()
@@ -862,6 +863,95 @@ def test_deep_window_kernel_equals_single_steps(lbm, nx, ny, chunk, nsteps, dept
         got, av = sim.download()
     assert np.array_equal(got, single)
     assert max_rel(av, av_single) < 2e-6
+
+
+def sparse_obstacles(rng, nx, ny, rows, cols, blocked=0.05):
+    """blocked cells only in the first `rows` rows and in the first `cols` columns: chunks of rows above the band are free
+    of them in every strip right of the columns, the periodic wrap brings the band back under the top chunks"""
+    ob = np.zeros((ny, nx), np.int32)
+    ob[:rows, :] = rng.random((rows, nx)) < blocked
+    ob[:, :cols] = rng.random((ny, cols)) < blocked
+    return ob
+
+
+@pytest.mark.parametrize("nx,ny,chunk", [(2048, 260, 0), (2048, 260, 24), (1024, 400, 40), (4096, 130, 16)])
+@pytest.mark.parametrize("nsteps", [6, 7, 8, 23])
+@pytest.mark.parametrize("pair", [0, 1])
+def test_deep_window_kernel_sweeps_without_obstacle_handling(lbm, nx, ny, chunk, nsteps, pair):
+    """the kernels instantiated per depth (6, 7, 8 timesteps per launch): a wave whose rows hold no blocked cell inside its
+    strip — looked up in a map of (strip, stored row) bits built from the obstacle map — runs deep_sweep<..., FREE>: no mask
+    loads, no per-level ballot.  Obstacles in a band of rows and a band of columns only, so that free and looking waves sit
+    side by side (and twins of different kinds share a workgroup); the accelerated row and the periodic wrap onto the band fall
+    into free-looking chunks.  Bit-identical to single steps, with the option on (default) and off."""
+    rng = np.random.default_rng(nx + 3 * ny + nsteps)
+    ob = sparse_obstacles(rng, nx, ny, 20, 200)
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
+    cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    for free in (1, 0):
+        with lbm.LBM(p, ob) as sim:
+            # (by default only launches of several rounds of units, or slabs without any blocked cell, run free sweeps)
+            opts = {"multistep": 0, "fuse": 8, "chunk_rows": chunk, "pair": pair, "nt_stores": 1, "free_sweeps": free}
+            if pair == 1:
+                opts["twin_steps"] = 8
+            for k, v in opts.items():
+                sim.set_option(k, v)
+            assert sim.get_option("fuse") == 8 and sim.get_option("pair") == pair and sim.get_option("free_sweeps") == free
+            sim.upload(cells0)
+            sim.run(nsteps)
+            got, av = sim.download()
+        assert np.array_equal(got, single), free
+        assert max_rel(av, av_single) < 2e-6
+
+
+def test_free_sweeps_follow_a_replaced_obstacle_map(lbm):
+    """lbm_upload_obstacles rebuilds the map the free sweeps look their rows up in: a context created on an EMPTY obstacle
+    map (every wave free) that is then handed a map with blocked cells must run like a context created on that map"""
+    rng = np.random.default_rng(123)
+    nx, ny, nsteps = 2048, 260, 16
+    ob = sparse_obstacles(rng, nx, ny, 30, 300)
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
+    cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, np.zeros_like(ob)) as sim:
+        for k, v in {"multistep": 0, "fuse": 8, "pair": 0, "nt_stores": 1}.items():
+            sim.set_option(k, v)
+        assert sim.get_option("free_sweeps") == 1     # nothing blocked: on by default
+        sim.upload_obstacles(ob)
+        assert sim.get_option("free_sweeps") == 0     # a one-round launch with blocked cells: off by default
+        sim.set_option("free_sweeps", 1)
+        sim.upload(cells0)
+        sim.run(nsteps)
+        got, av = sim.download()
+    assert np.array_equal(got, single)
+
+
+@pytest.mark.parametrize("pair,transport", [(-1, "peer"), (0, "peer"), (-1, "copy")])
+def test_row_slabs_free_sweeps(lbm, pair, transport, halo_defaults):
+    """the same in slab mode (d2q9_deep<..., PUSH> / d2q9_deep_twin<..., PUSH> and the two-stream launch sets): the map is in
+    stored-row coordinates, halo rows included; 8192x1408 over two slabs, blocked cells in a band of rows that straddles the
+    slab boundary and in a band of columns"""
+    halo_defaults(transport=transport)
+    rng = np.random.default_rng(78)
+    nx, ny, nsteps = 8192, 1408, 23
+    ob = np.zeros((ny, nx), np.int32)
+    ob[690:720, :] = rng.random((30, nx)) < 0.02
+    ob[:, 4000:4300] = rng.random((ny, 300)) < 0.02
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
+    cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob, devices=[0, 0]) as sim:
+        sim.set_option("pair", pair)
+        sim.set_option("free_sweeps", 1)
+        assert sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8 and sim.get_option("free_sweeps") == 1
+        sim.upload(cells0)
+        sim.run(nsteps)
+        many, av_many = sim.download()
+    assert np.array_equal(one, many)
+    assert max_rel(av_many, av_one) < 2e-6
 
 
 @pytest.mark.parametrize("nx,ny,chunk", [(256, 8, 0), (256, 37, 5), (512, 64, 32), (1024, 50, 7), (2048, 16, 16), (260, 33, 4),

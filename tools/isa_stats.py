@@ -115,7 +115,7 @@ def main():
         v, sp, lds, sg = meta.get(name, (0, 0, 0, 0))
         print("%s\n  vgpr %d  spilled %d  lds %d B  sgpr %d" % (name, v, sp, lds, sg))
         # the kernel, then its loops by arithmetic content (the row loops of the two sweep directions, general and steady form)
-        rows = [("kernel", ins)] + [("loop " + h, seq) for h, seq in sorted(per.items(), key=lambda kv: -sum(1 for x in kv[1] if x.startswith("v_pk")))[:4]]
+        rows = [("kernel", ins)] + [("loop " + h, seq) for h, seq in sorted(per.items(), key=lambda kv: -sum(1 for x in kv[1] if x.startswith("v_pk")))[:int(os.environ.get("ISA_LOOPS","4"))]]
         for label, seq in rows:
             c = Counter(classify(x.split()[0]) for x in seq)
             valu = sum(n for k, n in c.items() if k.startswith("v_") or k == "dpp")
