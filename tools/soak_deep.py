@@ -16,8 +16,10 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(7)
 w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
 cases = []
-for (nx, ny, nsteps) in ((1024, 1024, 23), (2048, 512, 19), (512, 300, 37), (4096, 1024, 16), (8192, 1408, 23)):  # (the last: slabs of 704 rows run chunk pairs)
+for (nx, ny, nsteps) in ((1024, 1024, 23), (2048, 512, 19), (512, 300, 37), (4096, 1024, 16), (8192, 1408, 23), (2048, 300, 24)):  # (8192x1408: slabs of 704 rows run chunk pairs)
     ob = (rng.random((ny, nx)) < 0.04).astype(np.int32)
+    if (nx, ny) in ((2048, 300), (8192, 1408)):   # blocked cells in a band of rows and a band of columns only: free sweeps next to looking ones
+        ob[40:, 256:] = 0
     cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
     p = lbm_amd.make_params(nx, ny, nsteps, obstacles=ob)
     with lbm_amd.LBM(p, ob) as sim:
@@ -31,7 +33,7 @@ variants = [dict(fuse=8, pair=0), dict(fuse=8, pair=1, twin_steps=5), dict(fuse=
             dict(fuse=6, pair=1, twin_steps=6), dict(fuse=8, pair=1, twin_steps=3), dict(fuse=8, pair=0, slabs=2), dict(fuse=8, pair=0, slabs=4)]
 # round 3: with non-temporal stores (what the big grids run) launches of exactly 5 / 6 / 7 / 8 timesteps take the kernels
 # instantiated per depth (steady form of the row loop); every variant once more in that configuration
-variants += [dict(v, nt_stores=1) for v in variants]
+variants += [dict(v, nt_stores=1, free_sweeps=1) for v in variants]   # (+ the map of blocked rows per strip consulted by every wave)
 t0, runs, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     for (nx, ny, nsteps, ob, cells0, p, ref, av_ref) in cases:
