@@ -928,11 +928,12 @@ def test_free_sweeps_follow_a_replaced_obstacle_map(lbm):
     assert np.array_equal(got, single)
 
 
-@pytest.mark.parametrize("pair,transport", [(-1, "peer"), (0, "peer"), (-1, "copy")])
-def test_row_slabs_free_sweeps(lbm, pair, transport, halo_defaults):
+@pytest.mark.parametrize("pair,transport,chunk", [(-1, "peer", 0), (0, "peer", 0), (-1, "copy", 0), (-1, "peer", 16), (0, "peer", 16)])
+def test_row_slabs_free_sweeps(lbm, pair, transport, chunk, halo_defaults):
     """the same in slab mode (d2q9_deep<..., PUSH> / d2q9_deep_twin<..., PUSH> and the two-stream launch sets): the map is in
     stored-row coordinates, halo rows included; 8192x1408 over two slabs, blocked cells in a band of rows that straddles the
-    slab boundary and in a band of columns"""
+    slab boundary and in a band of columns.  chunk = 16: chunks that short make the interior several rounds of units (the
+    tapered schedule the slabs of a 2-GPU run of 8192x8192 get), where the free sweeps are on without being asked for"""
     halo_defaults(transport=transport)
     rng = np.random.default_rng(78)
     nx, ny, nsteps = 8192, 1408, 23
@@ -945,7 +946,11 @@ def test_row_slabs_free_sweeps(lbm, pair, transport, halo_defaults):
     one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     with lbm.LBM(p, ob, devices=[0, 0]) as sim:
         sim.set_option("pair", pair)
-        sim.set_option("free_sweeps", 1)
+        if chunk:
+            sim.set_option("chunk_rows", chunk)
+        else:
+            assert sim.get_option("free_sweeps") == 0     # one round of units and blocked cells: off by default
+            sim.set_option("free_sweeps", 1)
         assert sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8 and sim.get_option("free_sweeps") == 1
         sim.upload(cells0)
         sim.run(nsteps)
