@@ -600,6 +600,9 @@ def main():
             return self_launch(args, sys.argv[1:])
         one_process = True   # no launcher on this machine (or asked for): INTEGRATION.md section 3's one-process form
 
+    # (the host driver supports dmabuf IPC only: without this RCCL and HIP IPC between ranks fail with hipIpcGetMemHandle:
+    # invalid argument; the GPU boxes export it already — a rank started by somebody else's launcher must not depend on that)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch  # device plumbing + torch.distributed (RCCL) only
     import lbm_amd
 
