@@ -18,10 +18,19 @@ all: $(LIB) $(EXE) $(EXE).exe oracle
 
 # lbm_version() carries a digest of the device + host sources the library was built from: a committed profile
 # (profiles/traffic.json) names the build it measured, and bench.py refuses its counters for any other build
-SRC_ID = $(shell cat $(PKG)/csrc/d2q9_kernels.h $(PKG)/csrc/halo_exchange.h $(PKG)/csrc/lbm_hip.cpp | sha256sum | cut -c1-12)
+CSRC   = $(PKG)/csrc/d2q9_kernels.h $(PKG)/csrc/deep_instances.h $(PKG)/csrc/halo_exchange.h $(PKG)/csrc/lbm_hip.cpp $(PKG)/csrc/lbm_deep.cpp
+SRC_ID = $(shell cat $(CSRC) | sha256sum | cut -c1-12)
 
-$(LIB): $(PKG)/csrc/lbm_hip.cpp $(PKG)/csrc/d2q9_kernels.h $(PKG)/csrc/halo_exchange.h include/lbm.h
-	$(HIPCC) $(HIPFLAGS) -DLBM_SRC_ID=\"$(SRC_ID)\" -shared $(PKG)/csrc/lbm_hip.cpp -o $@ -ldl
+# Two translation units: the deep window kernels get the compiler's max-ILP scheduling strategy (csrc/deep_instances.h says
+# why), everything else the default one.  The objects are build products next to the library (*.o is git-ignored).
+$(PKG)/csrc/lbm_hip.o: $(CSRC) include/lbm.h
+	$(HIPCC) $(HIPFLAGS) -DLBM_SRC_ID=\"$(SRC_ID)\" -c $(PKG)/csrc/lbm_hip.cpp -o $@
+
+$(PKG)/csrc/lbm_deep.o: $(PKG)/csrc/lbm_deep.cpp $(PKG)/csrc/deep_instances.h $(PKG)/csrc/d2q9_kernels.h
+	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-sched-strategy=max-ilp -c $(PKG)/csrc/lbm_deep.cpp -o $@
+
+$(LIB): $(PKG)/csrc/lbm_hip.o $(PKG)/csrc/lbm_deep.o
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared $^ -o $@ -ldl
 
 $(EXE): $(PKG)/host/d2q9-bgk.c include/lbm.h $(LIB)
 	$(CC) -std=c99 -O2 -Wall -D_GNU_SOURCE -Iinclude $(PKG)/host/d2q9-bgk.c -o $@ -L$(PKG) -llbm_hip -lm -lpthread -Wl,-rpath,'$$ORIGIN/$(PKG)'
@@ -60,7 +69,7 @@ tools/%: tools/%.cpp
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -I/opt/rocm/include $< -o $@
 
 clean:
-	rm -f $(LIB) $(EXE) $(EXE).exe $(EXE)-asan
+	rm -f $(LIB) $(PKG)/csrc/*.o $(EXE) $(EXE).exe $(EXE)-asan
 	$(MAKE) -C oracle clean
 
 .PHONY: all check clean oracle asan oracle-asan probes

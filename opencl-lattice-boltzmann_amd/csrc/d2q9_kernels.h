@@ -30,6 +30,8 @@
 // Not a translation of kernels.cl: different work decomposition (float4 rows, grid-stride,
 // wave64 shuffles), different arithmetic grouping (pairwise momentum differences, shared
 // equilibrium terms), fused accelerate, byte mask, deterministic two-stage reduction.
+// (The library is two translation units — lbm_hip.cpp and lbm_deep.cpp, see deep_instances.h —, so the kernels that are not
+// templates are `static`: only the unit that launches them emits them.)
 #pragma once
 #include <type_traits>
 
@@ -431,7 +433,7 @@ __device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned exp
   }
 }
 
-__global__ __launch_bounds__(kBlock) void halo_push(const PushArgs a) {
+static __global__ __launch_bounds__(kBlock) void halo_push(const PushArgs a) {
   const unsigned half = gridDim.x >> 1;  // first half of the workgroups: bottom rows, second half: top rows
   const bool hi = blockIdx.x >= half;
   const v4f *src = reinterpret_cast<const v4f *>(hi ? a.src_hi : a.src_lo);
@@ -492,7 +494,7 @@ __device__ __forceinline__ void spin_on_flags(const uint32_t *flags, uint32_t se
   if (threadIdx.x < 2) spin_on_flag(flags + threadIdx.x, seq, err, timeout);
 }
 
-__global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
+static __global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
   spin_on_flags(flags, seq, err, timeout);
 }
 
@@ -1749,7 +1751,7 @@ __device__ __forceinline__ void deep_sweep_rows(bool up, bool twinned, int L, in
 
 // The map strip_rows_clean reads: one wave per (strip, word of 64 rows); a lane looks at the mask bytes of its own two
 // cells, exactly as issue_pair_loads / deep_sweep address them (lanes beyond the grid's last column wrap).
-__global__ __launch_bounds__(64) void strip_row_bits(const uint8_t *mask, int nx, int rows, int strips, int lanes_out, int halo_lanes,
+static __global__ __launch_bounds__(64) void strip_row_bits(const uint8_t *mask, int nx, int rows, int strips, int lanes_out, int halo_lanes,
                                                      unsigned long long *bits, int words) {
   const int strip = blockIdx.x % strips, word = blockIdx.x / strips, lane = threadIdx.x;
   if (word >= words) return;
@@ -2371,7 +2373,7 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
 // One workgroup per buffered step: sums that step's per-workgroup partials in a fixed order into
 // av_sum[first + blockIdx.x] (double).  Replaces the reference's multi-pass reduce kernel
 // (kernels.cl:234-290) and its in-place pass results.
-__global__ __launch_bounds__(kBlock) void reduce_partials(const float *partials, int stride, int nb, double *av_sum) {
+static __global__ __launch_bounds__(kBlock) void reduce_partials(const float *partials, int stride, int nb, double *av_sum) {
   const float *p = partials + (size_t)blockIdx.x * stride;
   double acc = 0.0;
   for (int i = threadIdx.x; i < nb; i += kBlock) acc += (double)p[i];
@@ -2387,7 +2389,7 @@ __global__ __launch_bounds__(kBlock) void reduce_partials(const float *partials,
 }
 
 // ---- stand-alone accelerate_flow (kernels.cl:9-53): prologue of a run ---------------------------
-__global__ void accelerate_row(float *cells, unsigned long long plane_stride, unsigned long long row_stride,
+static __global__ void accelerate_row(float *cells, unsigned long long plane_stride, unsigned long long row_stride,
                                const uint8_t *mask, int nx, int row, float aw1, float aw2) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= nx) return;
@@ -2404,7 +2406,7 @@ __global__ void accelerate_row(float *cells, unsigned long long plane_stride, un
 }
 
 // ---- initial state on the device (values of d2q9-bgk.c:529-550) ---------------------------------
-__global__ void init_cells(float *cells, unsigned long long plane_stride, unsigned long long row_stride, int nx,
+static __global__ void init_cells(float *cells, unsigned long long plane_stride, unsigned long long row_stride, int nx,
                            size_t n, float w0, float w1, float w2) {
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
     const size_t y = c / nx;
@@ -2420,7 +2422,7 @@ __global__ void init_cells(float *cells, unsigned long long plane_stride, unsign
 // ---- read-back: row-interleaved device layout -> the reference's plane-major float[9][rows][nx] -------
 // (into the grid that is not current — scratch between runs — so that the device-to-host transfer is nine large
 // contiguous copies instead of 9*rows strided ones)
-__global__ void pack_planes(const float *cells, unsigned long long plane_stride, unsigned long long row_stride, int nx,
+static __global__ void pack_planes(const float *cells, unsigned long long plane_stride, unsigned long long row_stride, int nx,
                             size_t n, float *out) {
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
     const size_t y = c / nx;
@@ -2431,7 +2433,7 @@ __global__ void pack_planes(const float *cells, unsigned long long plane_stride,
 }
 
 // ---- output stage: columns of final_state.dat + velocity sum (d2q9-bgk.c:787-832, 396-442) ------
-__global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsigned long long plane_stride,
+static __global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsigned long long plane_stride,
                                                        unsigned long long row_stride, int nx, const uint8_t *mask,
                                                        size_t n, float density, float *u_x, float *u_y, float *u,
                                                        float *pressure, float *partials) {
@@ -2466,7 +2468,7 @@ __global__ __launch_bounds__(kBlock) void final_fields(const float *cells, unsig
 // ---- roofline denominator: float4 streaming copy ---------------------------------------------
 // VALU roofline calibration: eight independent chains of packed fp32 fused multiply-adds per thread — the instruction the
 // deep window kernel's collision is made of — so that the issue rate, not a dependency, bounds the loop.
-__global__ __launch_bounds__(kBlock) void valu_spin(float *out, int iters, float seed) {
+static __global__ __launch_bounds__(kBlock) void valu_spin(float *out, int iters, float seed) {
   v2f acc[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) acc[i] = splat2(seed + 0.125f * (float)i + 1e-3f * (float)(threadIdx.x & 7));
@@ -2484,13 +2486,13 @@ __global__ __launch_bounds__(kBlock) void valu_spin(float *out, int iters, float
   out[(size_t)blockIdx.x * kBlock + threadIdx.x] = s.x + s.y;
 }
 
-__global__ __launch_bounds__(kBlock) void copy_f4(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
+static __global__ __launch_bounds__(kBlock) void copy_f4(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = in[i];
 }
 
 // the same with the access pattern that proved best for the step kernels: one 4-KiB tile per workgroup,
 // non-temporal loads and stores
-__global__ __launch_bounds__(kBlock) void copy_f4_nt(const float *__restrict__ in, float *__restrict__ out, size_t n4) {
+static __global__ __launch_bounds__(kBlock) void copy_f4_nt(const float *__restrict__ in, float *__restrict__ out, size_t n4) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n4) {
     const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(in) + i);

@@ -18,6 +18,7 @@
 // interior work on the main stream; events join the two streams once per launch set.
 #include "../../include/lbm.h"
 #include "d2q9_kernels.h"
+#include "deep_instances.h"
 #include "halo_exchange.h"
 
 #include <dlfcn.h>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/isa_stats.py [file.s] [name-filter ...] — instruction mix of the step kernels from the gfx950 assembly.
 
-Without a file it compiles csrc/lbm_hip.cpp to assembly first (hipcc -S --cuda-device-only, ~15 s).  For every
+Without a file it compiles the library's two translation units to assembly first (hipcc -S --cuda-device-only, ~1 min).  For every
 kernel whose mangled name contains one of the filters (default: the default template instances of the multi-step
 kernels) it prints registers / LDS / spills from the metadata and the instruction classes of (a) the whole kernel
 and (b) its loops — the blocks the compiler's comments assign to each loop header — ordered by arithmetic content: the row
@@ -98,13 +98,17 @@ def main():
     path = args[0] if args and args[0].endswith(".s") else None
     filters = [a for a in args if not a.endswith(".s")] or DEFAULT
     if path is None:
-        path = os.path.join(tempfile.gettempdir(), "lbm_hip_gfx950.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I/opt/rocm/include", "-w",
-                        "-S", "--cuda-device-only", "-o", path, os.path.join(ROOT, "opencl-lattice-boltzmann_amd", "csrc", "lbm_hip.cpp")],
-                       check=True)
-    text = open(path).read()
+        # the library's two translation units with the flags the Makefile gives them (the deep window kernels: max-ILP scheduling)
+        text = ""
+        for src, extra in (("lbm_hip.cpp", []), ("lbm_deep.cpp", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])):
+            path = os.path.join(tempfile.gettempdir(), src.replace(".cpp", "_gfx950.s"))
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I/opt/rocm/include", "-w"] + extra +
+                           ["-S", "--cuda-device-only", "-o", path, os.path.join(ROOT, "opencl-lattice-boltzmann_amd", "csrc", src)], check=True)
+            text += open(path).read() + "\n"
+    else:
+        text = open(path).read()
     meta = {}
-    for b in text[text.find("amdhsa.kernels"):].split("  - .agpr_count")[1:]:
+    for b in text.split("  - .agpr_count")[1:]:
         nm = re.search(r"\.name:\s+(\S+)", b).group(1)
         meta[nm] = tuple(int(re.search(r"\.%s:\s+(\d+)" % k, b).group(1)) for k in
                          ("vgpr_count", "vgpr_spill_count", "group_segment_fixed_size", "sgpr_count"))
