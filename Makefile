@@ -30,7 +30,7 @@ $(PKG)/csrc/lbm_deep.o: $(PKG)/csrc/lbm_deep.cpp $(PKG)/csrc/deep_instances.h $(
 	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-sched-strategy=max-ilp -c $(PKG)/csrc/lbm_deep.cpp -o $@
 
 $(LIB): $(PKG)/csrc/lbm_hip.o $(PKG)/csrc/lbm_deep.o
-	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared $^ -o $@ -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -Wl,-z,defs $^ -o $@ -ldl   # -z defs: a launch of a deep kernel instance that LBM_DEEP_INSTANCES lacks fails HERE
 
 $(EXE): $(PKG)/host/d2q9-bgk.c include/lbm.h $(LIB)
 	$(CC) -std=c99 -O2 -Wall -D_GNU_SOURCE -Iinclude $(PKG)/host/d2q9-bgk.c -o $@ -L$(PKG) -llbm_hip -lm -lpthread -Wl,-rpath,'$$ORIGIN/$(PKG)'

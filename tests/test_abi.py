@@ -24,6 +24,27 @@ def test_library_exports_every_declared_symbol(lbm):
         assert hasattr(lib, s), s                   # and the .so exports it
 
 
+def test_every_launched_deep_kernel_instance_is_in_the_library(lbm):
+    """the deep window kernels live in a translation unit of their own (csrc/lbm_deep.cpp instantiates the list of
+    csrc/deep_instances.h, lbm_hip.cpp only declares them `extern template`): every instance lbm_hip.cpp launches must be on
+    that list — the link runs with -z defs, and the library must carry no undefined symbol of the lbm namespace"""
+    import subprocess
+    so = os.path.join(ROOT, "opencl-lattice-boltzmann_amd", "liblbm_hip.so")
+    undefined = subprocess.run(["nm", "-uC", so], capture_output=True, text=True, check=True).stdout
+    assert "lbm::" not in undefined, [ln for ln in undefined.splitlines() if "lbm::" in ln][:5]
+    src = open(os.path.join(ROOT, "opencl-lattice-boltzmann_amd", "csrc", "lbm_hip.cpp")).read()
+    listed = open(os.path.join(ROOT, "opencl-lattice-boltzmann_amd", "csrc", "deep_instances.h")).read()
+    launched = set(re.findall(r"hipLaunchKernelGGL\(\((d2q9_deep(?:_twin)?<[^>]*>)\)", src))
+    assert len(launched) == 34
+    consts = {"kDeepSteps": "8", "kDeepTwinSteps": "8", "kDeepTwinDefault": "5"}
+    n_listed = len(re.findall(r"X\(d2q9_deep", listed))
+    assert n_listed == len(launched), (n_listed, len(launched))
+    for inst in launched:      # same kernel family and depth at least (defaulted template arguments are spelled out in the list)
+        name, args = inst.split("<", 1)
+        first = consts.get(args.split(",")[0].strip(), args.split(",")[0].strip())
+        assert re.search(r"X\(%s<%s, " % (name, first), listed), inst
+
+
 def test_params_struct_matches_reference_t_param(lbm):
     # t_param: 4 floats + 4 ints = 32 bytes, 32-byte aligned in the reference (d2q9-bgk.c:81-92)
     assert ctypes.sizeof(lbm.Params) == 32
