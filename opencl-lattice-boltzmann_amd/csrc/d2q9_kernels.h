@@ -556,6 +556,14 @@ struct Step2Args {
   // are all clear runs the sweep without obstacle handling (deep_sweep<..., FREE>).  nullptr: no map, every wave looks.
   const unsigned long long *clean_bits;
   int clean_words;
+  // d2q9_deep / d2q9_deep_twin, one-round schedules with a few strips that are slow because they hold blocked cells in most
+  // rows (a cavity's wall strips): such a strip appears TWICE among the `strips` (virtual) strips of the interior decode, each
+  // copy working on one half of every chunk (pair) of the table — half the rows per wave, so that the launch does not end
+  // with the wall strips' waves.  vmap[2v] = the real strip of virtual strip v, vmap[2v+1] = its table t; vtab[2(t*nchunks +
+  // chunk)], [.. + 1] = first row and end of that chunk in table t (table 0: the plain schedule).  nullptr: strips are strips.
+  const int *vmap;
+  const int *vtab;
+  int strips_edge;             // real strips per row: what the EDGE units of a compact launch set are numbered by
 };
 
 // Which work unit a workgroup has (compact launch sets: edge schedule first).  All wave-uniform.
@@ -2050,9 +2058,20 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
   const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
   if (slot >= us.units_per_band) return;
   const int unit0 = band * us.units_per_band + slot;
-  const int chunk = unit0 / a.strips, strip = unit0 - chunk * a.strips;
+  const int sdiv = (PUSH && us.edge) ? a.strips_edge : a.strips;
+  const int chunk = unit0 / sdiv;
+  int strip = unit0 - chunk * sdiv;
   const int unit = unit0 + us.partial_off;  // slot of the velocity sums
-  const int ys = us.chunk_start[chunk], ye = us.chunk_start[chunk + 1];
+  int ys, ye;
+  if (a.vmap != nullptr && !(PUSH && us.edge)) {  // (virtual strips, see Step2Args)
+    const int *e = a.vtab + 2 * ((size_t)a.vmap[2 * strip + 1] * a.nchunks + chunk);
+    strip = a.vmap[2 * strip];
+    ys = e[0];
+    ye = e[1];
+  } else {
+    ys = us.chunk_start[chunk];
+    ye = us.chunk_start[chunk + 1];
+  }
   if (ys >= ye || chunk == us.skip) {
     if (lane < nlev) partials[(size_t)lane * pstride + unit] = 0.f;
     if constexpr (PUSH) {
@@ -2123,16 +2142,27 @@ __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, floa
   const int band = us.bid % us.nbands, slot = us.bid / us.nbands;
   if (slot >= us.units_per_band) return;  // units_per_band counts workgroups: chunk PAIRS x strips (edge: strips)
   const int punit = band * us.units_per_band + slot;
-  const int pair = punit / a.strips, strip = punit - pair * a.strips;
-  const int chunk = (PUSH && us.edge) ? 2 * wv : 2 * pair + wv;
-  const int unit = chunk * a.strips + strip + us.partial_off;
-  const int ys = us.chunk_start[chunk], ye = us.chunk_start[chunk + 1];
-  const int pys = us.chunk_start[chunk ^ 1], pye = us.chunk_start[(chunk ^ 1) + 1];
+  const bool edge_wg = PUSH && us.edge;
+  const int sdiv = edge_wg ? a.strips_edge : a.strips;
+  const int pair = punit / sdiv;
+  int strip = punit - pair * sdiv;
+  const int chunk = edge_wg ? 2 * wv : 2 * pair + wv;
+  const int unit = chunk * sdiv + strip + us.partial_off;
+  int ys, ye, pys, pye;
+  if (a.vmap != nullptr && !edge_wg) {  // (virtual strips, see Step2Args: a copy's chunks 2p / 2p+1 are the halves of one chunk)
+    const int *e = a.vtab + 2 * ((size_t)a.vmap[2 * strip + 1] * a.nchunks + chunk), *pe = e + (wv ? -2 : 2);
+    strip = a.vmap[2 * strip];
+    ys = e[0]; ye = e[1];
+    pys = pe[0]; pye = pe[1];
+  } else {
+    ys = us.chunk_start[chunk]; ye = us.chunk_start[chunk + 1];
+    pys = us.chunk_start[chunk ^ 1]; pye = us.chunk_start[(chunk ^ 1) + 1];
+  }
   const bool empty = ys >= ye || (!(PUSH && us.edge) && chunk == us.skip);
   const bool twinned = !(PUSH && us.edge) && !empty && pys < pye && (chunk ^ 1) != us.skip;  // the same on both waves
   if constexpr (PUSH) {
     // nobody works on the edge table's middle chunk (the interior): its slot of the velocity sums is this wave's to clear
-    if (us.edge && wv == 0 && lane < nlev) partials[(size_t)lane * pstride + (a.strips + strip + us.partial_off)] = 0.f;
+    if (us.edge && wv == 0 && lane < nlev) partials[(size_t)lane * pstride + (a.strips_edge + strip + us.partial_off)] = 0.f;
   }
   if (empty) {
     if (lane < nlev) partials[(size_t)lane * pstride + unit] = 0.f;

@@ -189,6 +189,11 @@ struct FuseGeom {
   int skip = -1;               // chunk whose units do nothing (the interior, in an edge schedule)
   bool single_round = false;   // all units of the launch are resident at once (equal chunks)
   bool paired = false;         // launched with the chunk-pair kernel (d2q9_step3p / d2q9_step4p)
+  // d2q9_deep, one-round schedules: strips that hold blocked cells in most rows appear twice, each copy on half of every
+  // chunk (Step2Args::vmap / vtab; balance_heavy_strips)
+  std::vector<int> starts;     // host copy of chunk_start
+  int vstrips = 0;             // strips of the interior decode (real strips + copies), 0 = not balanced
+  int *vmap = nullptr, *vtab = nullptr;
 };
 
 struct Slab {
@@ -220,6 +225,7 @@ struct Slab {
   unsigned long long *clean_bits = nullptr;  // d2q9_deep's strips x stored rows: which hold a blocked cell (lbm::strip_row_bits)
   int clean_words = 0;            // 64-row words per strip of that map
   bool all_clean = false;         // no blocked cell anywhere in the slab's stored rows
+  std::vector<int> heavy;         // d2q9_deep's strips with a blocked cell in most stored rows (a cavity's wall strips), if few
   int edge_rows = 0;              // rows at each slab edge that the edge launch computes (= halo depth)
   int m_tiles_x = 0, m_tiles_y = 0;  // tiles of d2q9_multi
   int m_tx = 32, m_ty = 16;          // its tile size (chosen by how many tiles the slab gives)
@@ -286,6 +292,8 @@ struct lbm_ctx {
   int steady = -1;          // d2q9_deep: 1 (and -1, auto) = launches of 6, 7 or 8 timesteps run the kernel instantiated for that depth (steady
                             // form of the row loop), 0 = the any-depth kernel always
   int obst_paths = -1;      // d2q9_deep: 1 (and -1, auto) = a second collision path without bounce-back selects for waves without blocked cells
+  int balance = -1;         // d2q9_deep, one-round schedules: 1 (and -1, auto) = strips that hold blocked cells in most rows get twice the waves
+                            // (balance_heavy_strips), 0 = every strip the same chunks
   int free_sweeps = -1;     // d2q9_deep at the depths with a kernel of their own: 1 (and -1, auto) = a wave whose rows hold no blocked cell in its
                             // strip runs the sweep without obstacle handling (the map of Slab::clean_bits), 0 = every wave looks level by level
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
@@ -375,6 +383,7 @@ constexpr long kTwinDeepCells = 3L << 20;
 // r03_scaling_projection.txt): 2048x1024 and 4096x512 (2M cells) 176 / 161 and 172 / 167; 2048x2048, 4096x1024, 8192x512
 // (4M) 209 / 244, 210 / 245, 201 / 238 -> from 3M cells (round 2, before the per-depth kernels: 5M).
 constexpr long kSlabDeepCells = 3L << 20;
+constexpr int kMaxHeavyStrips = 4;  // see build_clean_bits / balance_heavy_strips
 int twin_cap(const lbm_ctx *c) {
   if (c->twin_steps > 0) return c->twin_steps;
   return (long)c->p.nx * c->rows_min >= kTwinDeepCells ? kDeepTwinSteps : kDeepTwinDefault;
@@ -524,6 +533,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
   g.nchunks = chunks_per_band * g.nbands;
   g.units_per_band = chunks_per_band * strips;
   g.units = g.units_per_band * g.nbands;
+  g.starts = starts;
   if (set_dev(s)) return LBM_ERR_HIP;
   if (g.chunk_start) HIP_TRY(hipFree(g.chunk_start));
   g.chunk_start = nullptr;
@@ -570,6 +580,64 @@ int build_clean_bits(const lbm_ctx *c, Slab &s) {
   unsigned long long any = 0;
   for (unsigned long long w : host) any |= w;
   s.all_clean = any == 0;
+  // strips whose waves look at blocked cells in most of their rows run ~1.3 x as long per row as the others: candidates for
+  // balance_heavy_strips (a handful at most — a grid full of obstacles has nothing to balance against)
+  s.heavy.clear();
+  for (int st = 0; st < s.strips2; st++) {
+    long dirty = 0;
+    for (int w = 0; w < words; w++) dirty += __builtin_popcountll(host[(size_t)st * words + w]);
+    if (2 * dirty > s.ext_rows) s.heavy.push_back(st);
+  }
+  if ((int)s.heavy.size() > kMaxHeavyStrips) s.heavy.clear();
+  return LBM_OK;
+}
+
+void free_balance(FuseGeom &g) {
+  if (g.vmap) hipFree(g.vmap);
+  if (g.vtab) hipFree(g.vtab);
+  g.vmap = g.vtab = nullptr;
+  g.vstrips = 0;
+}
+
+// One-round schedule g of d2q9_deep (pairs: d2q9_deep_twin) over `strips` real strips: every heavy strip gets a second
+// (virtual) strip, and its two copies work on the two halves of every chunk — of every chunk PAIR for the twins, whose
+// chunks 2p / 2p+1 must stay neighbours: copy j takes chunk 2p+j of the plain table and splits it in the middle.  The
+// caller has planned the schedule's wave slots for strips + heavy.size() strips (g.units_per_band / g.units say so).
+int balance_heavy_strips(const Slab &s, FuseGeom &g, bool pairs, int strips, int nh) {
+  free_balance(g);
+  const int n = g.nchunks;
+  if (nh == 0) return LBM_OK;  // (option balance = 0, or nothing to balance: the schedule was planned for `strips` strips)
+  if (nh != (int)s.heavy.size() || (int)g.starts.size() != n + 1 || (pairs && (n & 1)))
+    return fail(LBM_ERR_STATE, "internal: schedule planned for %d heavy strips cannot be balanced", nh);
+  std::vector<int> vtab((size_t)3 * n * 2), vmap;
+  for (int ch = 0; ch < n; ch++) {
+    const int y0 = g.starts[ch], y1 = g.starts[ch + 1];
+    vtab[2 * ch] = y0;
+    vtab[2 * ch + 1] = y1;
+    if (!pairs) {
+      const int mid = y0 + (y1 - y0) / 2;
+      vtab[2 * (n + ch)] = y0;      vtab[2 * (n + ch) + 1] = mid;
+      vtab[2 * (2 * n + ch)] = mid; vtab[2 * (2 * n + ch) + 1] = y1;
+    }
+  }
+  if (pairs)
+    for (int p2 = 0; p2 < n; p2 += 2)
+      for (int j = 0; j < 2; j++) {
+        const int y0 = g.starts[p2 + j], y1 = g.starts[p2 + j + 1], mid = y0 + (y1 - y0) / 2;
+        int *t = &vtab[2 * ((size_t)(1 + j) * n + p2)];
+        t[0] = y0; t[1] = mid; t[2] = mid; t[3] = y1;
+      }
+  for (int st = 0; st < strips; st++) {
+    const bool heavy = std::find(s.heavy.begin(), s.heavy.end(), st) != s.heavy.end();
+    vmap.push_back(st);
+    vmap.push_back(heavy ? 1 : 0);
+    if (heavy) { vmap.push_back(st); vmap.push_back(2); }
+  }
+  if (set_dev(s)) return LBM_ERR_HIP;
+  if (dev_alloc(&g.vmap, vmap.size()) || dev_alloc(&g.vtab, vtab.size())) return LBM_ERR_HIP;
+  HIP_TRY(hipMemcpy(g.vmap, vmap.data(), vmap.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g.vtab, vtab.data(), vtab.size() * sizeof(int), hipMemcpyHostToDevice));
+  g.vstrips = strips + nh;
   return LBM_OK;
 }
 
@@ -580,7 +648,7 @@ int build_clean_bits(const lbm_ctx *c, Slab &s) {
 // the second set of loops costs instruction-cache room — 4096x4096 cavity 376 / 375, 8192x1024 slab 319 / 325, 8192x2048 361 / 368.
 const unsigned long long *clean_bits_for(const lbm_ctx *c, const Slab &s, const FuseGeom &g) {
   if (c->free_sweeps == 0 || !s.clean_bits) return nullptr;
-  if (c->free_sweeps < 0 && g.single_round && !s.all_clean) return nullptr;
+  if (c->free_sweeps < 0 && g.single_round && !s.all_clean && g.vstrips == 0) return nullptr;
   return s.clean_bits;
 }
 
@@ -595,8 +663,20 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
   s.lanes2 = std::min(lmax, (div_up(q2, s.strips2) + 7) / 8 * 8);
   const int c6max = std::max(8, std::min(c->chunk_rows > 0 ? c->chunk_rows : 96, s.rows));
   const int c6min = std::max(4, std::min(c->chunk_min > 0 ? c->chunk_min : 24, c6max));
+  free_balance(s.f6_main);
+  free_balance(s.f6_twin);
+  if (int rc = build_clean_bits(c, s)) return rc;
+  const int nh = c->balance != 0 ? (int)s.heavy.size() : 0;  // strips that get a second (virtual) strip in one-round schedules
+  // a one-round schedule planned for strips2 + nh strips, balanced; any other schedule as it is
+  auto one_slab_schedule = [&](FuseGeom &g, bool pairs) -> int {
+    if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2)) return rc;
+    if (nh == 0 || !g.single_round) return LBM_OK;
+    if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2 + nh)) return rc;
+    if (g.single_round) return balance_heavy_strips(s, g, pairs, s.strips2, nh);
+    return fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2);
+  };
   if (!c->halo_mode) {
-    if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_main, 2, 0, false, s.strips2)) return rc;
+    if (int rc = one_slab_schedule(s.f6_main, false)) return rc;
     s.nb_total = std::max(s.nb_total, s.f6_main.units);
     // chunk pairs (d2q9_deep_twin, at most kDeepTwinSteps per launch): where the launch is one round of units
     s.f6_twin.units = 0;
@@ -614,7 +694,11 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
         s.strips_tw = s.strips2;
         s.lanes_tw = s.lanes2;
       }
-      if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_twin, 2, 0, true, s.strips_tw)) return rc;
+      if (tw_cap <= kDeepTwinDefault) {
+        if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, s.f6_twin, 2, 0, true, s.strips_tw)) return rc;
+      } else if (int rc = one_slab_schedule(s.f6_twin, true)) {  // (the eight-step twins run d2q9_deep's strips)
+        return rc;
+      }
       s.f6_twin.paired = s.f6_twin.single_round || c->pair > 0 || (long)c->p.nx * c->rows_min >= kTwinDeepCells;
       if (s.f6_twin.paired) s.nb_total = std::max(s.nb_total, s.f6_twin.units);
     }
@@ -644,6 +728,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     // chunks of R - (edge iterations) rows: they are dispatched when the edge units retire and finish with the others.
     const int slots = s.cus * 4 * 2, edge_work = 2 * s.strips2, late_per_strip = 2;
     const int rows = i1 - i0, delay = s.edge_rows + 2 * (kDeepSteps - 1);
+    const int vs = s.strips2 + nh;  // the one-round schedules below plan their wave slots for the heavy strips' copies too
     // Chunk PAIRS for the interior (d2q9_deep_twin<..., PUSH>, compact launch sets only): a strip's edge rows are one
     // workgroup (wave 0: bottom edge, wave 1: top edge, both running alone for edge_rows + 2(D-1) iterations), the interior
     // n_pairs workgroups of two chunks of R rows that start at their common boundary (R + D-1 iterations) and, as the last
@@ -652,7 +737,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     // (two-stream launch sets — RCCL, copies — keep the lone kernel: an interior launch of pairs next to the edge launch and the
     // exchange kernel was measured at 200 against 292 GLUPS on the 8192x1024 ring of one: the 40-KB pair workgroups crowd them out)
     if (c->pair != 0 && c->edge_aware != 0 && compact_sets(c)) {
-      const int n_pairs = (slots - edge_work) / (2 * s.strips2);
+      const int n_pairs = (slots - edge_work) / (2 * vs);
       const int Rp = n_pairs > 0 ? div_up(rows + 2 * delay, 2 * n_pairs + 2) : 0;
       const int rp_late = Rp - delay;
       if (n_pairs >= 1 && Rp <= c6max && rp_late >= 4) {
@@ -672,19 +757,21 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
         FuseGeom &g = s.f6_main;
         g.nbands = 1;
         g.nchunks = nch;
-        g.units_per_band = g.nchunks * s.strips2;
+        g.units_per_band = g.nchunks * vs;
         g.units = g.units_per_band;
         g.single_round = true;
         g.paired = true;
+        g.starts = starts;
         if (g.chunk_start) HIP_TRY(hipFree(g.chunk_start));
         g.chunk_start = nullptr;
         if (dev_alloc(&g.chunk_start, starts.size())) return LBM_ERR_HIP;
         HIP_TRY(hipMemcpy(g.chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (int rc = balance_heavy_strips(s, g, true, s.strips2, nh)) return rc;
         s.nb_total = std::max(s.nb_total, s.f6_main.units + e.units);
         return LBM_OK;
       }
     }
-    const int n_full = (slots - edge_work) / s.strips2;
+    const int n_full = (slots - edge_work) / vs;
     const int R = n_full > 0 ? div_up(rows + late_per_strip * delay, n_full + late_per_strip) : 0;
     const int r_late = R - delay;
     if (c->edge_aware != 0 && n_full >= 2 && R <= c6max && r_late >= 4) {
@@ -704,14 +791,16 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
       FuseGeom &g = s.f6_main;
       g.nbands = 1;
       g.nchunks = n_full + late_per_strip;
-      g.units_per_band = g.nchunks * s.strips2;
+      g.units_per_band = g.nchunks * vs;
       g.units = g.units_per_band;
       g.single_round = true;
       g.paired = false;
+      g.starts = starts;
       if (g.chunk_start) HIP_TRY(hipFree(g.chunk_start));
       g.chunk_start = nullptr;
       if (dev_alloc(&g.chunk_start, starts.size())) return LBM_ERR_HIP;
       HIP_TRY(hipMemcpy(g.chunk_start, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
+      if (int rc = balance_heavy_strips(s, g, false, s.strips2, nh)) return rc;
     } else {
       // more rows than one round of units takes (the slabs of a 2-GPU run, of the weak-scaling leg): the tapered multi-round
       // schedule, as chunk pairs where the launch set is compact (measured on one slab without halo rows: 8192x4096 383 -> 405)
@@ -850,7 +939,6 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
       s.nb_total = std::max(s.nb_total, s.f4_main.units);
     }
     if (int rc = deep_geometry(c, s)) return rc;
-    if (int rc = build_clean_bits(c, s)) return rc;
   }
   return LBM_OK;
 }
@@ -928,6 +1016,8 @@ Step2Args base_args2(const lbm_ctx *c, const Slab &s, int src, bool accel_next, 
   a.strips = s.strips;
   a.lanes_out = s.lanes_out;
   a.chunk_start = g.chunk_start;
+  a.vmap = g.vmap;
+  a.vtab = g.vtab;
   a.nchunks = g.nchunks;
   a.nbands = g.nbands;
   a.units_per_band = g.units_per_band;
@@ -990,11 +1080,12 @@ void launch_step4(const lbm_ctx *c, const Step2Args &a0, float *partials3, float
 }
 
 // compact launch set of the three- / four-step kernels: edge units first, then the interior units, one launch
-void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, int units, float *partials, int nlev, hipStream_t st) {
+void launch_deep(const lbm_ctx *c, const Slab &s, const FuseGeom &g, const Step2Args &a0, int units, float *partials, int nlev, hipStream_t st) {
   Step2Args a = a0;
-  a.strips = s.strips2;
+  a.strips = g.vstrips > 0 ? g.vstrips : s.strips2;
+  a.strips_edge = s.strips2;
   a.lanes_out = s.lanes2;
-  a.clean_bits = clean_bits_for(c, s, s.f6_main);
+  a.clean_bits = clean_bits_for(c, s, s.f6_main);  // (an edge launch beside the interior launch follows the interior's policy)
   a.clean_words = s.clean_words;
   const dim3 grid(units), block(64);
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;  // (-1 auto = on)
@@ -1012,7 +1103,8 @@ void launch_deep(const lbm_ctx *c, const Slab &s, const Step2Args &a0, int units
 // compact launch set of d2q9_deep: the edge units first, then the interior units, ONE launch
 void launch_deep_compact(const lbm_ctx *c, const Slab &s, const Step2Args &a0, float *partials, int nlev, hipStream_t st) {
   Step2Args a = a0;
-  a.strips = s.strips2;
+  a.strips = s.f6_main.vstrips > 0 ? s.f6_main.vstrips : s.strips2;
+  a.strips_edge = s.strips2;
   a.lanes_out = s.lanes2;
   a.clean_bits = clean_bits_for(c, s, s.f6_main);
   a.clean_words = s.clean_words;
@@ -1043,7 +1135,8 @@ void launch_deep_compact(const lbm_ctx *c, const Slab &s, const Step2Args &a0, f
 
 void launch_deep_twin(const lbm_ctx *c, const Slab &s, const Step2Args &a0, float *partials, int nlev, hipStream_t st) {
   Step2Args a = a0;
-  a.strips = s.strips_tw;
+  a.strips = s.f6_twin.vstrips > 0 ? s.f6_twin.vstrips : s.strips_tw;
+  a.strips_edge = s.strips_tw;
   a.lanes_out = s.lanes_tw;
   a.units_per_band = a0.units_per_band / 2;  // chunk pairs x strips
   const dim3 grid(s.f6_twin.units / 2), block(128);
@@ -1360,7 +1453,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           launch_multi(s, a, s.m_tiles_y, s.s_main);
         } else if (kind == KIND_DEEP) {
           if (deep_twin) launch_deep_twin(c, s, base_args2(c, s, src, !last, s.f6_twin), slot1, adv, s.s_main);
-          else launch_deep(c, s, base_args2(c, s, src, !last, s.f6_main), s.f6_main.units, slot1, adv, s.s_main);
+          else launch_deep(c, s, s.f6_main, base_args2(c, s, src, !last, s.f6_main), s.f6_main.units, slot1, adv, s.s_main);
         } else if (kind == KIND_FUSED4) {
           Step2Args a = base_args2(c, s, src, !last, s.f4_main);
           a.partials1 = slot1;
@@ -1511,10 +1604,10 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       } else if (kind == KIND_DEEP) {
         Step2Args e = base_args2(c, s, src, !last, s.f6_edge);
         e.skip_chunk = s.f6_edge.skip;  // chunk table {bottom edge rows, (interior), top edge rows}
-        launch_deep(c, s, e, s.f6_edge.units, slot1 + s.f6_main.units, adv, s_edge);
+        launch_deep(c, s, s.f6_edge, e, s.f6_edge.units, slot1 + s.f6_main.units, adv, s_edge);
         HIP_TRY(hipGetLastError());
         if (s.f6_main.units > 0) {
-          launch_deep(c, s, base_args2(c, s, src, !last, s.f6_main), s.f6_main.units, slot1, adv, s.s_main);
+          launch_deep(c, s, s.f6_main, base_args2(c, s, src, !last, s.f6_main), s.f6_main.units, slot1, adv, s.s_main);
           HIP_TRY(hipGetLastError());
         }
       } else if (kind == KIND_FUSED4) {
@@ -1676,6 +1769,8 @@ void free_slab(Slab &s) {
   if (s.f6_main.chunk_start) hipFree(s.f6_main.chunk_start);
   if (s.f6_edge.chunk_start) hipFree(s.f6_edge.chunk_start);
   if (s.f6_twin.chunk_start) hipFree(s.f6_twin.chunk_start);
+  free_balance(s.f6_main);
+  free_balance(s.f6_twin);
   if (s.ev_t0) hipEventDestroy(s.ev_t0);
   if (s.ev_t1) hipEventDestroy(s.ev_t1);
   if (s.ev_aux) hipEventDestroy(s.ev_aux);
@@ -2242,11 +2337,11 @@ int lbm_upload(lbm_ctx *c, const float *cells) {
 int lbm_upload_obstacles(lbm_ctx *c, const int32_t *obstacles) {
   if (!c || !obstacles) return fail(LBM_ERR_ARG, "NULL argument");
   if (int rc = sync_all(c)) return rc;
-  for (Slab &s : c->slabs) {
+  for (Slab &s : c->slabs)
     if (int rc = upload_mask(c, s, obstacles)) return rc;
-    if (int rc = build_clean_bits(c, s)) return rc;
-  }
-  return LBM_OK;
+  // what the library derives from the map — the deep window kernel's bits of rows with blocked cells per strip, and with them
+  // which strips its one-round schedules balance — follows the new map
+  return rebuild_geometry(c);
 }
 
 int lbm_run(lbm_ctx *c, int nsteps) {
@@ -2484,6 +2579,12 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     c->obst_paths = (int)value;
     return LBM_OK;
   }
+  if (!strcmp(key, "balance")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "balance must be -1 (auto), 0 or 1");
+    if (int rc = sync_all(c)) return rc;
+    c->balance = (int)value;
+    return rebuild_geometry(c);
+  }
   if (!strcmp(key, "free_sweeps")) {
     if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "free_sweeps must be -1 (auto), 0 or 1");
     c->free_sweeps = (int)value;
@@ -2598,6 +2699,15 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "steady")) *value = c->steady != 0;
+  else if (!strcmp(key, "balance")) {
+    // strips of the context's deep window kernel that got a second (virtual) strip
+    *value = 0;
+    if (!c->slabs.empty() && fuse_level(c) >= kDeepMin) {
+      const Slab &s0 = c->slabs[0];
+      const FuseGeom &g = (!c->halo_mode && deep_twin_effective(c)) ? s0.f6_twin : s0.f6_main;
+      *value = g.vstrips > 0 ? g.vstrips - (g.vstrips == 0 ? 0 : s0.strips2) : 0;
+    }
+  }
   else if (!strcmp(key, "free_sweeps")) {
     // are the launches of the context's deep window kernel given the map?
     *value = 0;

@@ -905,6 +905,69 @@ def test_deep_window_kernel_sweeps_without_obstacle_handling(lbm, nx, ny, chunk,
         assert max_rel(av, av_single) < 2e-6
 
 
+def walls(nx, ny, rng=None, extra=0):
+    """side walls only (what a rank's slab of a cavity looks like), optionally a few blocked cells elsewhere"""
+    ob = np.zeros((ny, nx), np.int32)
+    ob[:, 0] = ob[:, -1] = 1
+    if extra:
+        ob[rng.integers(0, ny, extra), rng.integers(0, nx, extra)] = 1
+    return ob
+
+
+@pytest.mark.parametrize("nx,ny", [(2048, 260), (4096, 131), (1024, 400)])
+@pytest.mark.parametrize("nsteps", [8, 23])
+@pytest.mark.parametrize("pair,nt,balance", [(1, 1, -1), (0, 1, -1), (1, -1, -1), (0, -1, -1), (1, 1, 0)])
+def test_one_round_schedules_balance_wall_strips(lbm, nx, ny, nsteps, pair, nt, balance):
+    """a launch that is ONE round of units ends with its slowest waves — those of the strips that hold blocked cells in most
+    rows, a cavity's two wall strips.  Such strips get a second (virtual) strip: two waves per chunk, each on half of its
+    rows (of a chunk PAIR for the twins, whose halves must stay neighbours).  Side walls + a few blocked cells elsewhere:
+    bit-identical to single steps, lone kernel and twins, per-depth and any-depth kernels, free sweeps on beside it"""
+    rng = np.random.default_rng(nx + ny + nsteps)
+    ob = walls(nx, ny, rng, extra=20)
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
+    cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    single, av_single = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob) as sim:
+        opts = {"multistep": 0, "fuse": 8, "pair": pair, "nt_stores": nt, "balance": balance}
+        if pair == 1:
+            opts["twin_steps"] = 8
+        for k, v in opts.items():
+            sim.set_option(k, v)
+        assert sim.get_option("fuse") == 8 and sim.get_option("pair") == pair
+        assert sim.get_option("balance") == (2 if balance else 0)           # the two wall strips
+        assert sim.get_option("free_sweeps") == (1 if balance else 0)       # balanced: the free waves are the critical path
+        sim.upload(cells0)
+        sim.run(nsteps)
+        got, av = sim.download()
+    assert np.array_equal(got, single)
+    assert max_rel(av, av_single) < 2e-6
+
+
+@pytest.mark.parametrize("pair,transport,balance", [(-1, "peer", -1), (0, "peer", -1), (-1, "copy", -1), (-1, "peer", 0), (0, "copy", 0)])
+def test_row_slabs_balance_wall_strips(lbm, pair, transport, balance, halo_defaults):
+    """the same for a rank's slab (compact launch sets with chunk pairs, with the lone kernel, and the two-stream sets):
+    8192x1408 with side walls over two slabs — what every rank of a row-partitioned cavity runs"""
+    halo_defaults(transport=transport)
+    rng = np.random.default_rng(79)
+    nx, ny, nsteps = 8192, 1408, 23
+    ob = walls(nx, ny, rng, extra=50)
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
+    cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob, devices=[0, 0]) as sim:
+        sim.set_option("pair", pair)
+        sim.set_option("balance", balance)
+        assert sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8
+        assert sim.get_option("balance") == (2 if balance else 0) and sim.get_option("free_sweeps") == (1 if balance else 0)
+        sim.upload(cells0)
+        sim.run(nsteps)
+        many, av_many = sim.download()
+    assert np.array_equal(one, many)
+    assert max_rel(av_many, av_one) < 2e-6
+
+
 def test_free_sweeps_follow_a_replaced_obstacle_map(lbm):
     """lbm_upload_obstacles rebuilds the map the free sweeps look their rows up in: a context created on an EMPTY obstacle
     map (every wave free) that is then handed a map with blocked cells must run like a context created on that map"""
@@ -920,8 +983,8 @@ def test_free_sweeps_follow_a_replaced_obstacle_map(lbm):
             sim.set_option(k, v)
         assert sim.get_option("free_sweeps") == 1     # nothing blocked: on by default
         sim.upload_obstacles(ob)
-        assert sim.get_option("free_sweeps") == 0     # a one-round launch with blocked cells: off by default
-        sim.set_option("free_sweeps", 1)
+        # a one-round launch with blocked cells: on only because the few strips that are blocked in most rows get balanced
+        assert sim.get_option("balance") > 0 and sim.get_option("free_sweeps") == 1
         sim.upload(cells0)
         sim.run(nsteps)
         got, av = sim.download()
@@ -949,7 +1012,8 @@ def test_row_slabs_free_sweeps(lbm, pair, transport, chunk, halo_defaults):
         if chunk:
             sim.set_option("chunk_rows", chunk)
         else:
-            assert sim.get_option("free_sweeps") == 0     # one round of units and blocked cells: off by default
+            # one round of units and blocked cells: on by default only where the strips blocked in most rows are few and balanced
+            assert sim.get_option("free_sweeps") == (1 if sim.get_option("balance") else 0)
             sim.set_option("free_sweeps", 1)
         assert sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8 and sim.get_option("free_sweeps") == 1
         sim.upload(cells0)
