@@ -213,6 +213,10 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  wave slots of the edge launch, 0 = slots reserved for the whole launch set
  *   "obst_paths"   deep window kernel: 1 (and -1, auto) = waves that hold no blocked cell take a collision path without
  *                  the bounce-back selects, 0 = one path
+ *   "balance"      deep window kernel, launches that are one round of work units: 1 (and -1, auto) = the strips that hold blocked
+ *                  cells in most rows (at most four: a cavity's wall strips) are worked on by twice the waves, each on half of
+ *                  every chunk of rows, so that the launch does not end with them; 0 = every strip the same.  Reads back as
+ *                  the number of strips doubled.  Same results bit for bit.
  *   "free_sweeps"  deep window kernel at 6, 7, 8 timesteps per launch: 1 (and -1, auto) = a wave whose chunk of rows holds no
  *                  blocked cell inside its strip (looked up in a map built from the obstacle map) sweeps it without any
  *                  obstacle handling, 0 = every wave looks level by level ("obst_paths").  Same results bit for bit.
