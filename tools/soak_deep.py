@@ -18,8 +18,11 @@ w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 
 cases = []
 for (nx, ny, nsteps) in ((1024, 1024, 23), (2048, 512, 19), (512, 300, 37), (4096, 1024, 16), (8192, 1408, 23), (2048, 300, 24)):  # (8192x1408: slabs of 704 rows run chunk pairs)
     ob = (rng.random((ny, nx)) < 0.04).astype(np.int32)
-    if (nx, ny) in ((2048, 300), (8192, 1408)):   # blocked cells in a band of rows and a band of columns only: free sweeps next to looking ones
-        ob[40:, 256:] = 0
+    if (nx, ny) in ((2048, 300), (8192, 1408)):   # blocked cells in a band of rows and a band of columns only: free sweeps next to looking
+        ob[40:, 256:] = 0                          # ones, and the strips of the column band (blocked in every row) balanced in one-round launches
+    if (nx, ny) == (4096, 1024):                  # a cavity's side walls + a sprinkle: the two wall strips balanced
+        ob[:] = (rng.random((ny, nx)) < 0.00002)
+        ob[:, 0] = ob[:, -1] = 1
     cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
     p = lbm_amd.make_params(nx, ny, nsteps, obstacles=ob)
     with lbm_amd.LBM(p, ob) as sim:
