@@ -19,10 +19,13 @@ def main():
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     nx, ny, nsteps, fuse, multistep, sync = (int(v) for v in sys.argv[1:7])
+    walls = len(sys.argv) > 7 and sys.argv[7] == "walls"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(33)
-    ob = (rng.random((ny, nx)) < 0.04).astype(np.int32)
+    ob = (rng.random((ny, nx)) < (0.00001 if walls else 0.04)).astype(np.int32)
     ob[0, :] = ob[-1, :] = 0
+    if walls:       # a cavity's side walls: every rank's one-round launch sets balance the two wall strips and run free sweeps
+        ob[:, 0] = ob[:, -1] = 1
     w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
     cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
     p = lbm_amd.make_params(nx, ny, nsteps, obstacles=ob)
@@ -41,6 +44,8 @@ def main():
     sim.set_option("halo_sync", sync)
     sim.set_option("fuse", fuse)
     sim.set_option("multistep", multistep)
+    if walls:
+        assert sim.get_option("balance") == 2 and sim.get_option("free_sweeps") == 1
     sim.upload(cells0)
     dist.barrier()
     # split runs: the exchange counter runs on across lbm_run calls, ranks drift apart in between

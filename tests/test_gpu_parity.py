@@ -317,7 +317,9 @@ def test_transport_self_ring(transport):
                                                                    (4, 2048, 256, 30, 4, 0, 2), (3, 1024, 300, 25, 3, 0, 2),
                                                                    # slabs of 704 / 1400 rows: the interior runs as chunk pairs (d2q9_deep_twin<..., PUSH>),
                                                                    # one round with a late pair / the tapered multi-round schedule
-                                                                   (2, 8192, 1408, 23, 8, 0, 0), (3, 8192, 4200, 16, 8, 0, 2)])
+                                                                   (2, 8192, 1408, 23, 8, 0, 0), (3, 8192, 4200, 16, 8, 0, 2),
+                                                                   # ... with a cavity's side walls: balanced wall strips + free sweeps on every rank
+                                                                   (2, 8192, 1408, 23, 8, 0, "walls"), (3, 8192, 2112, 16, 8, 0, "walls")])
 def test_peer_transport_between_processes(world, nx, ny, nsteps, fuse, multistep, sync):
     """the peer transport across PROCESS boundaries: `world` processes share the one GPU, each owns a row slab, maps
     its neighbours' grids and flag words through HIP IPC, pushes its edge rows into them and waits on its own flags
@@ -330,7 +332,7 @@ def test_peer_transport_between_processes(world, nx, ny, nsteps, fuse, multistep
         port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_ipc_ring.py"),
-                        str(nx), str(ny), str(nsteps), str(fuse), str(multistep), str(sync)],
+                        str(nx), str(ny), str(nsteps), str(fuse), str(multistep)] + (["0", "walls"] if sync == "walls" else [str(sync)]),
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     if r.returncode != 0 or "ipc-ring ok" not in r.stdout:
         print(r.stdout[-3000:])
