@@ -383,6 +383,7 @@ constexpr long kTwinDeepCells = 3L << 20;
 // r03_scaling_projection.txt): 2048x1024 and 4096x512 (2M cells) 176 / 161 and 172 / 167; 2048x2048, 4096x1024, 8192x512
 // (4M) 209 / 244, 210 / 245, 201 / 238 -> from 3M cells (round 2, before the per-depth kernels: 5M).
 constexpr long kSlabDeepCells = 3L << 20;
+constexpr int kOneRoundRows = 160;   // d2q9_deep: longest chunk of a one-round schedule (see deep_geometry)
 constexpr int kMaxHeavyStrips = 4;  // see build_clean_bits / balance_heavy_strips
 int twin_cap(const lbm_ctx *c) {
   if (c->twin_steps > 0) return c->twin_steps;
@@ -463,7 +464,8 @@ bool compact_sets(const lbm_ctx *c) {
 // `cmax` rows and ends with ever shorter ones (guided self-scheduling), down to `cmin`.  (R full rounds of equal
 // chunks instead of the taper: within +-2 % on 8192x1024 ... 8192x8192, no consistent sign — not adopted.)
 int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_bands, FuseGeom &g, int waves_per_simd = 2,
-                  int reserve = 0, bool pairs = false, int strips_of_kernel = 0) {
+                  int reserve = 0, bool pairs = false, int strips_of_kernel = 0, int cmax_one = 0) {
+  if (cmax_one < cmax) cmax_one = cmax;  // longest chunk of a ONE-round schedule (d2q9_deep: longer than the tapered schedules' first chunks)
   const int rows = r1 - r0;
   const int strips = strips_of_kernel > 0 ? strips_of_kernel : s.strips;
   g.nbands = (allow_bands && rows >= 8 * 4 * cmin) ? 8 : 1;
@@ -485,7 +487,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
       const int fl = pairs ? std::max(2, (int)std::floor((double)waves_resident / nb / strips) & ~1)
                            : std::max(1, (int)std::floor((double)waves_resident / nb / strips));
       const int nrows = div_up(rows, nb);
-      if ((int)std::ceil((double)nrows / fl) > cmax) continue;  // not a one-round schedule with this band count
+      if ((int)std::ceil((double)nrows / fl) > cmax_one) continue;  // not a one-round schedule with this band count
       const double busy = (double)std::min(fl, nrows) * nb * (1.0 + 0.01 * nb);
       if (busy > best) { best = busy; best_nb = nb; }
     }
@@ -509,7 +511,7 @@ int fuse_schedule(const Slab &s, int r0, int r1, int cmax, int cmin, bool allow_
     // with fewer, "one round" of 64-row chunks was 2192 units on 1500 free slots and the last workgroups started when the
     // first had finished: compact 8192x1024 slab 212 instead of 220 GLUPS)
     const bool fits = (double)waves_resident / g.nbands / strips >= (pairs ? 2.0 : 1.0);
-    const bool single_round = one_round <= cmax && fits;
+    const bool single_round = one_round <= cmax_one && fits;
     if (b == 0) g.single_round = single_round;
     while (rem > 0) {
       int sz = single_round ? std::max(2, one_round) : (int)std::ceil(rem / (2.0 * slots));
@@ -663,17 +665,23 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
   s.lanes2 = std::min(lmax, (div_up(q2, s.strips2) + 7) / 8 * 8);
   const int c6max = std::max(8, std::min(c->chunk_rows > 0 ? c->chunk_rows : 96, s.rows));
   const int c6min = std::max(4, std::min(c->chunk_min > 0 ? c->chunk_min : 24, c6max));
+  // A launch of ONE round of units may have longer chunks than the first chunks of the tapered multi-round schedule: a grid
+  // that needs 1.2 or 1.5 rounds of 96-row chunks ends with a long, half-empty second round.  Same box, cavity, tapered / one
+  // round (profiles/r03_balance.txt): 8192x3072 397 / 444 GLUPS (118-row chunks), 8192x4096 426 / 451 (158); from about two
+  // rounds on nothing is left to gain (8192x5120 441 / 450, 8192x6144 453 / 462, 8192x8192 470 / 471) or lost (6144x6144, 181-row
+  // chunks: 435 / 424) -> one round up to 160 rows per chunk.
+  const int c6one = c->chunk_rows > 0 ? c6max : std::max(c6max, std::min(kOneRoundRows, s.rows));
   free_balance(s.f6_main);
   free_balance(s.f6_twin);
   if (int rc = build_clean_bits(c, s)) return rc;
   const int nh = c->balance != 0 ? (int)s.heavy.size() : 0;  // strips that get a second (virtual) strip in one-round schedules
   // a one-round schedule planned for strips2 + nh strips, balanced; any other schedule as it is
   auto one_slab_schedule = [&](FuseGeom &g, bool pairs) -> int {
-    if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2)) return rc;
+    if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2, c6one)) return rc;
     if (nh == 0 || !g.single_round) return LBM_OK;
-    if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2 + nh)) return rc;
+    if (int rc = fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2 + nh, c6one)) return rc;
     if (g.single_round) return balance_heavy_strips(s, g, pairs, s.strips2, nh);
-    return fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2);
+    return fuse_schedule(s, 0, s.rows, c6max, c6min, true, g, 2, 0, pairs, s.strips2, c6one);
   };
   if (!c->halo_mode) {
     if (int rc = one_slab_schedule(s.f6_main, false)) return rc;
@@ -740,7 +748,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
       const int n_pairs = (slots - edge_work) / (2 * vs);
       const int Rp = n_pairs > 0 ? div_up(rows + 2 * delay, 2 * n_pairs + 2) : 0;
       const int rp_late = Rp - delay;
-      if (n_pairs >= 1 && Rp <= c6max && rp_late >= 4) {
+      if (n_pairs >= 1 && Rp <= c6one && rp_late >= 4) {
         std::vector<int> starts;
         int y = i0, left = rows;
         const int nch = 2 * n_pairs + 2;
@@ -774,7 +782,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     const int n_full = (slots - edge_work) / vs;
     const int R = n_full > 0 ? div_up(rows + late_per_strip * delay, n_full + late_per_strip) : 0;
     const int r_late = R - delay;
-    if (c->edge_aware != 0 && n_full >= 2 && R <= c6max && r_late >= 4) {
+    if (c->edge_aware != 0 && n_full >= 2 && R <= c6one && r_late >= 4) {
       std::vector<int> starts;
       int y = i0, left = rows;
       for (int k = 0; k < n_full + late_per_strip; k++) {
@@ -804,7 +812,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     } else {
       // more rows than one round of units takes (the slabs of a 2-GPU run, of the weak-scaling leg): the tapered multi-round
       // schedule, as chunk pairs where the launch set is compact (measured on one slab without halo rows: 8192x4096 383 -> 405)
-      const bool pairs = c->pair != 0 && compact_sets(c) && rows > (long)c6max * n_full;
+      const bool pairs = c->pair != 0 && compact_sets(c) && rows > (long)c6one * n_full;
       if (int rc = fuse_schedule(s, i0, i1, c6max, c6min, true, s.f6_main, 2, 2 * edge_work, pairs, s.strips2)) return rc;
       s.f6_main.paired = pairs;
     }
