@@ -782,7 +782,8 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     const int n_full = (slots - edge_work) / vs;
     const int R = n_full > 0 ? div_up(rows + late_per_strip * delay, n_full + late_per_strip) : 0;
     const int r_late = R - delay;
-    if (c->edge_aware != 0 && n_full >= 2 && R <= c6one && r_late >= 4) {
+    if (c->edge_aware != 0 && n_full >= 2 && R <= c6max && r_late >= 4) {  // (the lone kernel's two-stream sets: 8192x4096 over RCCL 433 GLUPS
+                                                                            // tapered, 389 as one round of 153-row chunks — c6max, not c6one)
       std::vector<int> starts;
       int y = i0, left = rows;
       for (int k = 0; k < n_full + late_per_strip; k++) {
@@ -812,7 +813,7 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     } else {
       // more rows than one round of units takes (the slabs of a 2-GPU run, of the weak-scaling leg): the tapered multi-round
       // schedule, as chunk pairs where the launch set is compact (measured on one slab without halo rows: 8192x4096 383 -> 405)
-      const bool pairs = c->pair != 0 && compact_sets(c) && rows > (long)c6one * n_full;
+      const bool pairs = c->pair != 0 && compact_sets(c) && rows > (long)c6max * n_full;
       if (int rc = fuse_schedule(s, i0, i1, c6max, c6min, true, s.f6_main, 2, 2 * edge_work, pairs, s.strips2)) return rc;
       s.f6_main.paired = pairs;
     }
