@@ -647,7 +647,10 @@ int balance_heavy_strips(const Slab &s, FuseGeom &g, bool pairs, int strips, int
 // several rounds of units — 8192x8192 cavity 463 / 446 — or nothing in the slab is blocked — no obstacles at all: 8192x8192
 // 476 / 456, 4096x4096 410 / 397, the 8192x1024 slab of an 8-GPU run 344 / 327.  A ONE-round launch that has blocked cells ends
 // with its slowest waves, the ones that look (the two wall strips of a cavity): the free waves' saving buys nothing there and
-// the second set of loops costs instruction-cache room — 4096x4096 cavity 376 / 375, 8192x1024 slab 319 / 325, 8192x2048 361 / 368.
+// the second set of loops costs instruction-cache room — 4096x4096 cavity 376 / 375, 8192x1024 slab 319 / 325, 8192x2048 361 / 368 —
+// unless the schedule takes those strips out of the critical path (balance_heavy_strips, g.vstrips > 0): then the free waves
+// are what the launch ends with, and the free sweeps pay again (8192x1024 slab with side walls 380-391 / 373,
+// profiles/r03_balance.txt).
 const unsigned long long *clean_bits_for(const lbm_ctx *c, const Slab &s, const FuseGeom &g) {
   if (c->free_sweeps == 0 || !s.clean_bits) return nullptr;
   if (c->free_sweeps < 0 && g.single_round && !s.all_clean && g.vstrips == 0) return nullptr;
@@ -2714,7 +2717,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
     if (!c->slabs.empty() && fuse_level(c) >= kDeepMin) {
       const Slab &s0 = c->slabs[0];
       const FuseGeom &g = (!c->halo_mode && deep_twin_effective(c)) ? s0.f6_twin : s0.f6_main;
-      *value = g.vstrips > 0 ? g.vstrips - (g.vstrips == 0 ? 0 : s0.strips2) : 0;
+      *value = g.vstrips > 0 ? g.vstrips - s0.strips2 : 0;
     }
   }
   else if (!strcmp(key, "free_sweeps")) {
