@@ -15,7 +15,16 @@ BASELINE.json (only the four border lines blocked), uniform rest initial state, 
 row-partitioned over N ranks (one process per GPU); the halo rows move inside liblbm_hip.so — by peer stores over
 xGMI into the neighbours' HIP-IPC-mapped grids and by RCCL send/recv, both measured back to back, the faster one is
 `value` — and the velocity sums by an RCCL all-reduce; the RCCL id and the peer descriptors are distributed with
-torch.distributed.  Prints ONE JSON line on rank 0.
+torch.distributed.  Prints ONE JSON line on rank 0 — with N ranks two: the headline record (`"partial"` set) as soon as the
+timed leg and its check are done, and the full record, which repeats it and adds the side legs, as the LAST line: a run cut
+off at somebody's time limit still leaves a valid record behind.
+
+Before anything is timed on N ranks, every halo transport has to pass three checks (`transport_check`): the reference's
+1024x1024 obstacles over the ranks for 400 steps against the oracle (>= 50 exchanges, the small-slab kernels), an
+8192 x 768N grid for 40 steps against the oracle (the deep window kernels with their in-kernel push / two-stream RCCL
+launch sets: what the headline leg runs), and on the timed geometry itself 32 steps from a seeded state whose per-slab
+digests must be bit-identical between the transports (or to the undivided grid).  A transport that fails one of them is
+neither timed nor reported.
 
 What the roofline object means (every field is recomputable from the others and from profiles/):
   a launch of the dominant kernel advances S timesteps and must read the grid once and write it once, whatever S is:
@@ -70,6 +79,68 @@ def make_workload(name, nx, ny):
         assert nx % 1024 == 0 and ny % 1024 == 0
         return np.tile(ob, (ny // 1024, nx // 1024))
     raise ValueError(name)
+
+
+T_START = time.time()
+
+
+def log(msg, rank=0):
+    """progress on stderr (rank 0): a long multi-rank run says where it is, with the seconds since it started"""
+    if rank == 0:
+        print("bench.py [%6.1f s] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+def seeded_state(nx, rows_global, density=0.1, amp=0.2, period=61, seed=2026):
+    """Deterministic non-equilibrium state of the given GLOBAL rows, float32[9, len(rows), nx]: w_k * density * (1 +- amp/2),
+    an integer hash of (speed, row mod 61, column).  Any rank computes exactly the rows it needs and any two ranks the same
+    values for the same row; 61 divides no slab height, so the rows either side of every slab boundary differ from each other
+    and from what they were a few steps earlier — a stale or misplaced halo row cannot pass for the right one."""
+    rows_global = np.asarray(rows_global, dtype=np.int64)
+    mask = np.uint64(0xFFFFFFFF)
+    x = np.arange(nx, dtype=np.uint64)[None, :]
+    r = np.arange(period, dtype=np.uint64)[:, None]
+    w = [4.0 / 9.0] + [1.0 / 9.0] * 4 + [1.0 / 36.0] * 4
+    tile = np.empty((9, period, nx), dtype=np.float32)
+    for k in range(9):
+        h = (r * np.uint64(0x9E3779B1) + x * np.uint64(0x85EBCA77) + np.uint64(((k + 1) * 0xC2B2AE3D + seed) & 0xFFFFFFFF)) & mask
+        h ^= h >> np.uint64(15)
+        h = (h * np.uint64(0x2C1B3C6D)) & mask
+        h ^= h >> np.uint64(12)
+        h = (h * np.uint64(0x297A2D39)) & mask
+        h ^= h >> np.uint64(15)
+        tile[k] = (w[k] * density * (1.0 + amp * (h.astype(np.float64) / 4294967296.0 - 0.5))).astype(np.float32)
+    return np.ascontiguousarray(tile[:, rows_global % period, :])
+
+
+def band_oracle(orc, nx, ny, obstacles, y0, y1, nsteps, density, accel, omega, state_fn=seeded_state):
+    """The fp32 oracle for global rows [y0, y1) of an nx x ny periodic grid over nsteps timesteps, computed on a BAND of rows:
+    the rows themselves plus nsteps + 1 rows either side — their domain of dependence (kernels.cl:104-112: one row per
+    step); what the band's own periodic wrap lets in at its two ends travels one row per step and stops short of them.
+    Returns (cells float32[9, y1 - y0, nx] after nsteps, raw float64[nsteps]: the sum of |j|/rho over these rows' fluid
+    cells per step, kernels.cl:198 before the division by the free cells).  A rank of an N-rank check pays for its own
+    slab, not for the whole grid."""
+    rows, margin = y1 - y0, nsteps + 1
+    if rows + 2 * margin >= ny:
+        band, off = np.arange(ny), y0
+    else:
+        band, off = np.arange(y0 - margin, y1 + margin) % ny, margin
+    nb = len(band)
+    src = np.ascontiguousarray(state_fn(nx, band), dtype=np.float32)
+    dst = np.empty_like(src)
+    obb = np.ascontiguousarray(obstacles[band], dtype=np.int32)
+    po = orc.make_params(nx, nb, max(nsteps, 1), 10, density, accel, omega)
+    accel_rows = [int(i) for i in np.nonzero(band == ny - 2)[0]]   # kernels.cl:18: global row ny-2, if the band holds it
+    raw = np.zeros(nsteps, dtype=np.float64)
+    for t in range(nsteps):
+        for a in accel_rows:
+            orc.accelerate_row(po, src, obb, a)
+        if off > 0:
+            orc.timestep_rows(po, src, dst, obb, 0, off)
+        raw[t] = orc.timestep_rows(po, src, dst, obb, off, off + rows)
+        if off + rows < nb:
+            orc.timestep_rows(po, src, dst, obb, off + rows, nb)
+        src, dst = dst, src
+    return src[:, off:off + rows], raw
 
 
 # ---- CPU baseline: the oracle (CPU restatement of the reference's timestep) on this box's host cores ----------
@@ -203,6 +274,13 @@ def max_over_ranks(dist, values, device):
     t = torch.tensor(values, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t]
+
+
+def sum_over_ranks(dist, values, device):
+    import torch
+    t = torch.tensor(np.asarray(values, dtype=np.float64), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
 
 
 def min_over_ranks(dist, value, device):
@@ -387,45 +465,67 @@ def max_rel(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)))
 
 
-def transport_check(env, transports, nsteps=64):
-    """Every halo transport against the ORACLE before any of them is timed or chosen: the reference's 1024x1024
-    obstacles row-partitioned over the ranks (128 rows each at 8 GPUs), a seeded random non-equilibrium state — every
-    slab boundary carries non-trivial data from the first step on, unlike a cavity at rest — 64 timesteps (8 exchanges
-    of 8 halo rows).  Each rank compares its own rows of every distribution (<= 2e-5 relative) and the all-reduced
-    av_vels record (<= 1e-4) with the fp32 oracle's (oracle/d2q9_oracle.c restating kernels.cl:9-231), computed on this
-    rank's host cores.  A transport that delivers stale, misplaced or late halo rows over xGMI fails here and is
-    neither timed nor reported as `value`."""
+def fault_legs():
+    """TEST HOOK: LBM_BENCH_FAULT=stale_halo[@leg,leg] makes one halo exchange of the named check legs ("small", "deep",
+    "digest"; none named = all three) deliver nothing (library option debug_stale_exchange) — the checks must catch it"""
+    f = os.environ.get("LBM_BENCH_FAULT", "")
+    if not f.startswith("stale_halo"):
+        return set()
+    return set(f.split("@", 1)[1].split(",")) if "@" in f else {"small", "deep", "digest"}
+
+
+def upload_rows(sim, nx, ny, y0, y1, rows):
+    """this rank's rows of a global initial state: the ABI takes the GLOBAL float[9][ny][nx] array and reads rows [y0, y1) of
+    it — the other rows are never touched, so they are never committed (np.empty: untouched pages cost nothing)"""
+    cells = np.empty((9, ny, nx), dtype=np.float32)
+    cells[:, y0:y1] = rows
+    sim.upload(cells)
+
+
+def oracle_leg(env, label, p, ob, transports, nsteps, fault):
+    """One check leg against the ORACLE: the nx x ny grid of `p` row-partitioned over the ranks, a seeded non-equilibrium state
+    (every slab boundary carries non-trivial data from the first step on, unlike a cavity at rest), nsteps timesteps on every
+    transport.  Each rank holds its own rows of every distribution (<= 2e-5 relative) and the all-reduced av_vels record
+    (<= 1e-4) against the fp32 oracle (oracle/d2q9_oracle.c restating kernels.cl:9-231) of ITS rows, computed on its own host
+    cores on a band of rows (band_oracle)."""
     from oracle.oracle import Oracle
-    lbm_amd = env.lbm
-    p2, ob2 = shipped("1024x1024")
-    p2.max_iters = nsteps + 8
-    rng = np.random.default_rng(2026)
-    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
-    cells0 = (w * (1.0 + 0.2 * (rng.random((9, 1024, 1024)) - 0.5))).astype(np.float32)
+    nx, ny = p.nx, p.ny
+    y0, rows = env.lbm.slab_rows(ny, env.world, env.rank)
+    y1 = y0 + rows
     os.environ["OMP_NUM_THREADS"] = str(max(1, min(8, len(os.sched_getaffinity(0)) // max(1, env.world))))
     orc = Oracle("f32", omp=True)
-    po = orc.make_params(1024, 1024, nsteps, p2.reynolds_dim, p2.density, p2.accel, p2.omega)
-    orc.set_obstacles(po, ob2)
-    ref = cells0.copy()
-    av_ref = orc.run(po, ref, ob2, nsteps)
+    t0 = time.perf_counter()
+    ref, raw = band_oracle(orc, nx, ny, ob, y0, y1, nsteps, p.density, p.accel, p.omega)
+    raw_all = sum_over_ranks(env.dist, raw, env.device) if env.dist is not None else raw
+    av_ref = (raw_all * float(p.free_cells_inv)).astype(np.float32)     # kernels.cl:202: sum * FREE_CELLS_INV
+    t_oracle = time.perf_counter() - t0
+    state0 = seeded_state(nx, np.arange(y0, y1))
     out = {}
     for tr in transports:
         res, rs = {}, None
         try:
-            rs = RankSim(env, p2, ob2, tr)
-            rs.sim.upload(cells0)
+            rs = RankSim(env, p, ob, tr)
+            assert rs.sim.row_range() == (y0, y1)
+            if fault:
+                rs.sim.set_option("debug_stale_exchange", 3)
+            upload_rows(rs.sim, nx, ny, y0, y1, state0)
             rs.sim.run(nsteps)
             synced(env, rs.sim)
             got = rs.sim.download(av_vels=False)[0]
             av = rs.av_vels()
-            y0, y1 = rs.sim.row_range()
-            ec, ea = max_rel(got[:, y0:y1], ref[:, y0:y1]), max_rel(av, av_ref)
+            ec, ea = max_rel(got[:, y0:y1], ref), max_rel(av, av_ref)
+            del got
             ec, ea = max_over_ranks(env.dist, [ec, ea], env.device)
+            o = {k: rs.sim.get_option(k) for k in ("fuse", "pair", "launch_steps", "multistep", "halo_depth", "compact")}
             res = {"ok": bool(ec < 2e-5 and ea < 1e-4), "cells_max_rel": float("%.3g" % ec), "av_vels_max_rel": float("%.3g" % ea),
-                   "halo_depth": rs.sim.get_option("halo_depth")}
+                   "halo_depth": o["halo_depth"], "exchanges": -(-nsteps // max(1, o["launch_steps"])),
+                   "kernel": ("d2q9_multi" if o["multistep"] else "d2q9_deep%s" % ("_twin" if o["pair"] else "") if o["fuse"] >= 6 else
+                              "d2q9_step%d%s" % (max(o["launch_steps"], 1), "p" if o["pair"] else "")) + (", compact launch sets" if o["compact"] else ", two streams")}
+            if tr == "peer":
+                res["push_release"] = rs.sim.get_option("push_release")
         except TransportFailed as e:
             res = {"ok": False, "error": str(e)[:300]}
-            print("bench.py: rank %d: transport %s failed the oracle check: %s" % (env.rank, tr, str(e)[:300]), file=sys.stderr, flush=True)
+            print("bench.py: rank %d: transport %s failed the oracle check (%s): %s" % (env.rank, tr, label, str(e)[:300]), file=sys.stderr, flush=True)
         except BaseException:
             if rs is not None:
                 rs.abandon()
@@ -433,8 +533,116 @@ def transport_check(env, transports, nsteps=64):
         if rs is not None:
             rs.close()
         out[tr] = res
-    return {"workload": "input_1024x1024 obstacles, seeded random state, %d timesteps, rows x%d, vs the fp32 oracle "
-                        "(cells <= 2e-5, av_vels <= 1e-4 relative)" % (nsteps, env.world), "transports": out}
+        log("transport_check %s: %s %s" % (label, tr, json.dumps(res)), env.rank)
+    return {"workload": "%s: %dx%d, rows x%d, seeded non-equilibrium state, %d timesteps vs the fp32 oracle of each rank's rows (cells <= 2e-5, "
+                        "av_vels <= 1e-4 relative)" % (label, nx, ny, env.world, nsteps),
+            "oracle_s": round(t_oracle, 2), "transports": out}
+
+
+def slab_digest(cells, y0, y1):
+    """128-bit digest of rows [y0, y1) of all nine planes of a float32[9][ny][nx] array"""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for k in range(9):
+        h.update(np.ascontiguousarray(cells[k, y0:y1]).data)
+    return h.digest()
+
+
+def digest_leg(env, params, obstacles, transports, nsteps, fault):
+    """The check on the TIMED geometry itself, bit for bit and without an oracle: every transport advances the timed grid
+    nsteps timesteps from the same seeded state, every rank digests its slab, the digests are gathered.  All kernels inline
+    one collision and a cell's result does not depend on which slab or launch computed it, so the slabs' digests must be
+    IDENTICAL between the transports — and identical to the digests of the same rows of the undivided grid, which rank 0
+    computes on its own GPU whenever there are not two transports to hold against each other, or they disagree."""
+    lbm_amd = env.lbm
+    nx, ny = params.nx, params.ny
+    y0, rows = lbm_amd.slab_rows(ny, env.world, env.rank)
+    y1 = y0 + rows
+    state0 = seeded_state(nx, np.arange(y0, y1))
+    digests, out = {}, {}
+    for tr in transports:
+        rs, res = None, {}
+        try:
+            rs = RankSim(env, params, obstacles, tr)
+            if fault:
+                rs.sim.set_option("debug_stale_exchange", 3)
+            upload_rows(rs.sim, nx, ny, y0, y1, state0)
+            rs.sim.run(nsteps)
+            synced(env, rs.sim)
+            got = rs.sim.download(av_vels=False)[0]
+            d = slab_digest(got, y0, y1)
+            del got
+            digests[tr] = gather_blobs(env.dist, d, env.world, env.device)
+            res = {"ok": True}
+        except TransportFailed as e:
+            res = {"ok": False, "error": str(e)[:300]}
+        except BaseException:
+            if rs is not None:
+                rs.abandon()
+            raise
+        if rs is not None:
+            rs.close()
+        out[tr] = res
+    names = list(digests)
+    agree = len(names) >= 2 and all(digests[t] == digests[names[0]] for t in names[1:])
+    reference = None
+    if names and not agree:
+        # the undivided grid on rank 0's GPU: one slab, no halo rows, no transport (the other ranks wait in the gather)
+        blob = bytes(16 * env.world)
+        if env.rank == 0:
+            with lbm_amd.LBM(params, obstacles) as sim:
+                sim.upload(seeded_state(nx, np.arange(ny)))
+                sim.run(nsteps)
+                whole = sim.download(av_vels=False)[0]
+            parts = []
+            for r in range(env.world):
+                r0, rn = lbm_amd.slab_rows(ny, env.world, r)
+                parts.append(slab_digest(whole, r0, r0 + rn))
+            blob = b"".join(parts)
+            del whole
+        blob = gather_blobs(env.dist, blob, env.world, env.device)[0]
+        reference = [blob[16 * r:16 * r + 16] for r in range(env.world)]
+    for tr in names:
+        bad = [r for r in range(env.world) if digests[tr][r] != (reference[r] if reference is not None else digests[names[0]][r])]
+        out[tr] = {"ok": not bad, "digest_rank0": digests[tr][0].hex()}
+        if bad:
+            out[tr]["ranks_that_differ"] = bad
+            print("bench.py: rank %d: transport %s: the slabs of ranks %s differ from %s after %d steps on the timed geometry"
+                  % (env.rank, tr, bad, "the undivided grid" if reference is not None else names[0], nsteps), file=sys.stderr, flush=True)
+    log("transport_check digest: %s" % json.dumps(out), env.rank)
+    return {"workload": "the timed %dx%d grid, rows x%d, seeded non-equilibrium state, %d timesteps: per-slab digests (blake2b-128 of "
+                        "the nine planes) identical %s" % (nx, ny, env.world, nsteps,
+                        "to the undivided grid's (one slab on rank 0)" if reference is not None else "between the transports"),
+            "compared_with": "undivided grid" if reference is not None else "each other", "transports": out}
+
+
+def transport_check(env, params, obstacles, transports):
+    """Every halo transport through three checks before any of them is timed or chosen (module docstring): `small` — the
+    reference's 1024x1024 obstacles for 400 steps (>= 50 exchanges of up to 8 halo rows; at 8 GPUs 128-row slabs on the
+    LDS-tile kernel and its edge-tile push), `deep` — 8192 x 768N cells with side walls for 40 steps (slabs of 6M cells: the
+    deep window kernels in the form the 8192x8192 leg runs them at 4 and 8 GPUs — one round of chunk pairs with push_chunk_pairs
+    and the per-wave publisher over peer stores, the lone kernel on two streams over RCCL —, five exchanges of 8 rows; the record
+    names the kernel that ran), both against the oracle; `digest` — the timed geometry, 32 steps,
+    bit for bit.  A transport is `ok` only if it passed all three."""
+    lbm_amd = env.lbm
+    faults = fault_legs()
+    legs = {}
+    p2, ob2 = shipped("1024x1024")
+    p2.max_iters = 400 + 8
+    legs["small"] = oracle_leg(env, "small", p2, ob2, transports, 400, "small" in faults)
+    nyd = 768 * env.world
+    obd = np.zeros((nyd, 8192), dtype=np.int32)
+    obd[:, 0] = obd[:, -1] = 1
+    pd = lbm_amd.make_params(8192, nyd, 48, 10, 0.1, 0.005, 1.85, obd)
+    legs["deep"] = oracle_leg(env, "deep", pd, obd, transports, 40, "deep" in faults)
+    del obd
+    legs["digest"] = digest_leg(env, params, obstacles, transports, 32, "digest" in faults)
+    verdict = {}
+    for tr in transports:
+        ok = all(legs[k]["transports"].get(tr, {}).get("ok", False) for k in legs)
+        verdict[tr] = dict(legs["small"]["transports"].get(tr, {}), ok=ok,
+                           failed_legs=[k for k in legs if not legs[k]["transports"].get(tr, {}).get("ok", False)])
+    return {"transports": verdict, "legs": legs, "fault_injected": sorted(faults) if faults else None}
 
 
 def result_check(av_gpu, av_oracle, tol=1e-4):
@@ -459,30 +667,41 @@ def free_port():
 def self_launch(args, argv):
     """`python bench.py --gpus N` without a launcher around it: start the ranks as a child process.  This process never
     imports the HIP library and never touches the GPU (a process that has may not be replaced or forked safely on this
-    pool); it relays rank 0's JSON line and the exit code."""
+    pool).  It STREAMS the child's output: every record line ({"metric"...) goes to stdout the moment rank 0 prints it — the
+    headline record first, the full record last — everything else to stderr; the exit code is the child's."""
+    import threading
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
-    env = dict(os.environ, LBM_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ, LBM_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               PYTHONUNBUFFERED="1")
     env.setdefault("OMP_NUM_THREADS", "8")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=env, start_new_session=True)
+    records = []
+
+    def relay():
+        for ln in proc.stdout:
+            ln = ln.rstrip("\n")
+            if ln.startswith('{"metric"'):
+                records.append(ln)
+                print(ln, flush=True)
+            else:
+                print(ln, file=sys.stderr, flush=True)
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
     try:
-        out, _ = proc.communicate(timeout=args.launch_timeout)
+        proc.wait(timeout=args.launch_timeout)
     except subprocess.TimeoutExpired:
         os.killpg(proc.pid, 9)     # exactly the process group started above
-        out, _ = proc.communicate()
-        sys.stdout.write(out or "")
-        raise SystemExit("bench.py --gpus %d: the ranks did not finish within %d s" % (args.gpus, args.launch_timeout))
-    lines = (out or "").splitlines()
-    for ln in lines:
-        if not ln.startswith('{"metric"'):
-            print(ln, file=sys.stderr)
-    js = [ln for ln in lines if ln.startswith('{"metric"')]
-    if js:
-        print(js[-1], flush=True)
+        proc.wait()
+        th.join(timeout=10)
+        raise SystemExit("bench.py --gpus %d: the ranks did not finish within %d s (%d record line(s) had been printed by then)"
+                         % (args.gpus, args.launch_timeout, len(records)))
+    th.join(timeout=30)
     if proc.returncode != 0:
         raise SystemExit("bench.py --gpus %d: the ranks started with torch.distributed.run exited with code %d (their messages are above)"
                          % (args.gpus, proc.returncode))
-    if not js:
+    if not records:
         raise SystemExit("bench.py --gpus %d: rank 0 printed no result line" % args.gpus)
 
 
@@ -520,7 +739,7 @@ def kernel_shape(opts):
     """(fused, deep, twin, multistep) from a context's read-back options"""
     fused = {0: 0, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[opts["fuse"]]   # timesteps per launch of the dominant kernel (0: one)
     deep = fused >= 6
-    twin = bool(deep and opts["pair"])   # d2q9_deep_twin (chunk pairs, at most five steps per launch)
+    twin = bool(deep and opts["pair"])   # d2q9_deep_twin (chunk pairs: up to five steps per launch below 3M cells, up to eight from there)
     if deep:
         fused = opts["launch_steps"]
     return fused, deep, twin, opts["multistep"]
@@ -546,14 +765,24 @@ def attach_traffic(rf, lups, nx, ny, deep, twin, steps_per_launch, model_bytes, 
     rf["traffic"] = tb
     rf["traffic_measured_in_run"] = False
     rf["traffic_source"] = ent.get("source")
-    rf["traffic_frac"] = round(tb / launch_s / 1e9 / HBM_PEAK_GBPS, 4)
+    # The bytes were counted on launches of ONE depth (the profile's own run: steps_per_launch, launch_us); this run may have
+    # cut its steps into launches of other depths (20 steps = 7 + 7 + 6).  Price the bytes on the duration of the launches
+    # they were counted on; without that record, on this run's launches only if they have the profile's depth.
+    spl, lus = ent.get("steps_per_launch"), ent.get("launch_us")
+    if lus:
+        rf["traffic_frac"] = round(tb / (lus * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+        rf["traffic_launch"] = {"steps_per_launch": spl, "launch_us": lus, "what": "the profiled launches the bytes were counted on"}
+    elif spl is None or abs(rf["steps_per_launch"] - spl) < 1e-9:
+        rf["traffic_frac"] = round(tb / launch_s / 1e9 / HBM_PEAK_GBPS, 4)
+    else:
+        rf["traffic_frac"] = None
     rf["traffic_over_model"] = round(tb / model_bytes, 4)
     if ent.get("evidence"):
         rf["bound_evidence"] = ent["evidence"]
         # `bound` names the roofline `frac` is priced against (the metric's: HBM); which resource the
         # kernel actually runs out of first is read off the counters of the committed profile
         vs = ent["evidence"].get("valu_issue_share")
-        if vs is not None:
+        if vs is not None and rf["traffic_frac"] is not None:
             rf["limited_by"] = "valu_issue" if vs > rf["traffic_frac"] else "hbm"
     if valu_tera:
         # issue-rate roofline: VALU lane-instructions the kernel executes per lattice update (committed profile) x rate
@@ -586,6 +815,9 @@ def main():
                          "with N ranks as a child process (torchrun also for N = 1: the rank path on one GPU); one-process = "
                          "one process drives N slabs (lbm_create(ndev=N))")
     ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the self-launched ranks get")
+    ap.add_argument("--budget-s", type=float, default=600.0,
+                    help="N > 1: a side leg (1024x1024 strong scaling, weak scaling) is started only while the run is younger than this "
+                         "many seconds; the headline record is printed before them either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip `value_cold` (the same steps before any calibration launch)")
     ap.add_argument("--no-extra", action="store_true", help="skip the 1024x1024, weak-scaling and reference-rule side measurements")
@@ -703,8 +935,10 @@ def main():
     tcheck, transports = None, [None]
     if rank_mode:
         want = ["peer"] if rehearsal else {"both": ["rccl", "peer"], "peer": ["peer"], "rccl": ["rccl"]}[args.transport]
-        tcheck = transport_check(env, want)
+        log("checking transports %s on %d rank(s) before anything is timed" % (want, world), rank)
+        tcheck = transport_check(env, params, obstacles, want)
         transports = [t for t in want if tcheck["transports"][t]["ok"]]
+        log("transports that passed: %s" % transports, rank)
 
     # ---- the timed region(s): one per halo transport, the faster one is reported as `value` -----------------------
     if rank_mode:
@@ -770,24 +1004,50 @@ def main():
         if b.get("per_rank"):
             out["per_rank_launch_set_us"] = b["per_rank"]
 
+    def judge_result():
+        """`result_ok`: av_vels of the timed context against the oracle's record of the same steps"""
+        if not av_oracle:
+            # no baseline leg in this run: a few steps of the OpenMP build of the same oracle, for the check alone
+            os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, len(os.sched_getaffinity(0)) // max(1, world))))
+            oracle_rate("f32", nx, ny, obstacles, args.accel, 6.0, 8, omp=True, av_out=av_oracle)
+        good_ok, detail = result_check(good[best]["av"], np.array(av_oracle))
+        out["result_ok"] = good_ok
+        out["result_check"] = detail
+        return good_ok
+
+    if rank == 0 and out is not None and good and rank_mode:
+        # ---- N ranks: the headline record NOW, before the side legs — a run that is cut off later has left it behind
+        ok = judge_result()
+        print(json.dumps(dict(out, partial="headline record; the full record (side legs `also`, `weak`) is the last line of this run")),
+              flush=True)
+        log("headline record printed: %s MLUPS over %s, result_ok %s" % (out["value"], out.get("transport"), ok), rank)
+
+    def side_leg_allowed(name):
+        """the ranks' common decision (a collective) whether a side leg still starts within --budget-s"""
+        late = max_over_ranks(dist, [time.time() - T_START], coll_device)[0] > args.budget_s
+        if late and rank == 0 and out is not None:
+            out.setdefault("skipped_legs", []).append("%s: the run was older than --budget-s %.0f s" % (name, args.budget_s))
+        return not late
+
     extra = not args.no_extra and (nx, ny) != (1024, 1024)
     if extra and rank_mode and transports:
-        # ---- the 1024x1024 input of the reference row-partitioned over the same ranks (BASELINE config 4: strong scaling)
-        p2, ob2 = shipped("1024x1024")
-        n2, w2 = 4000, 400
-        p2.max_iters = n2 + w2 + 256
-        r2 = rank_leg(env, p2, ob2, transports, w2, n2, before=pre_warm)
-        g2 = {k: v for k, v in r2.items() if "wall_s" in v}
-        if rank == 0 and out is not None and g2:
-            b2 = min(g2, key=lambda k: g2[k]["wall_s"])
-            out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat, rows x%d (strong scaling of the reference's "
-                                       "largest input)" % world,
-                           "value": round(1024 * 1024 * n2 / g2[b2]["wall_s"] / 1e6, 1), "unit": "MLUPS", "steps": n2, "warmup": w2, "transport": b2,
-                           "transports": {k: (round(1024 * 1024 * n2 / v["wall_s"] / 1e6, 1) if "wall_s" in v else v) for k, v in r2.items()},
-                           "us_per_step": round(g2[b2]["wall_s"] / n2 * 1e6, 3), "halo_depth": g2[b2]["options"]["halo_depth"],
-                           "per_rank_launch_set_us": g2[b2].get("per_rank")}
+        if side_leg_allowed("also"):
+            # ---- the 1024x1024 input of the reference row-partitioned over the same ranks (BASELINE config 4: strong scaling)
+            p2, ob2 = shipped("1024x1024")
+            n2, w2 = 4000, 400
+            p2.max_iters = n2 + w2 + 256
+            r2 = rank_leg(env, p2, ob2, transports, w2, n2, before=pre_warm)
+            g2 = {k: v for k, v in r2.items() if "wall_s" in v}
+            if rank == 0 and out is not None and g2:
+                b2 = min(g2, key=lambda k: g2[k]["wall_s"])
+                out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat, rows x%d (strong scaling of the reference's "
+                                           "largest input)" % world,
+                               "value": round(1024 * 1024 * n2 / g2[b2]["wall_s"] / 1e6, 1), "unit": "MLUPS", "steps": n2, "warmup": w2, "transport": b2,
+                               "transports": {k: (round(1024 * 1024 * n2 / v["wall_s"] / 1e6, 1) if "wall_s" in v else v) for k, v in r2.items()},
+                               "us_per_step": round(g2[b2]["wall_s"] / n2 * 1e6, 3), "halo_depth": g2[b2]["options"]["halo_depth"],
+                               "per_rank_launch_set_us": g2[b2].get("per_rank")}
         # ---- BASELINE config 5's weak-scaling leg: every rank holds args.ny rows of an nx x (ny * N) cavity
-        if args.scaling == "strong":
+        if args.scaling == "strong" and side_leg_allowed("weak"):
             nyw = args.ny * world
             obw = make_workload(args.workload, nx, nyw)
             nw, ww = min(args.steps, 96), min(args.warmup, 16)
@@ -848,18 +1108,22 @@ def main():
             ref = {}
             p3 = lbm_amd.make_params(nx, ny, args.steps, 10, 0.1, args.accel, 1.85, obstacles)
             with lbm_amd.LBM(p3, obstacles) as s3:
+                # the read-back targets exist before the clock starts, as in the reference (malloc in initialise(),
+                # d2q9-bgk.c:519-526) — page-locked (lbm_host_alloc), which is what host/d2q9-bgk.c does too
+                hb = lbm_amd.HostBuffer((4, ny, nx))
                 t1 = time.perf_counter()
                 s3.upload(None)
                 s3.run(args.steps)
                 s3.sync()
                 s3.download(cells=False)
-                s3.final_state()
+                s3.final_state(out=hb.array)
                 s3.reynolds()
                 tr = time.perf_counter() - t1
+                hb.close()
             ref["headline_grid"] = {"value": round(nx * ny * args.steps / tr / 1e6, 1), "unit": "MLUPS", "steps": args.steps,
                                     "elapsed_s": round(tr, 4),
                                     "what": "device-side initial state + %d steps + av_vels + the four final_state columns "
-                                            "(%.2f GB to pageable host memory) + Reynolds number, wall clock" % (args.steps, 4 * nx * ny * 4 / 1e9)}
+                                            "(%.2f GB to page-locked host memory, lbm_host_alloc) + Reynolds number, wall clock" % (args.steps, 4 * nx * ny * 4 / 1e9)}
             try:
                 with tempfile.TemporaryDirectory() as d:
                     r = subprocess.run([os.path.join(ROOT, "d2q9-bgk.exe"), os.path.join(ROOT, "inputs", "input_1024x1024.params"),
@@ -875,13 +1139,8 @@ def main():
         # ---- CPU baseline (rank 0, N = 1 only) and the oracle record `result_ok` is judged on -------------------------
         if world == 1 and ndev == 1 and not args.no_cpu_baseline and not rank_mode:
             out["cpu_baseline"] = cpu_baseline(nx, ny, obstacles, args.accel, av_out=av_oracle)
-        if not av_oracle:
-            # no baseline leg in this run: a few steps of the OpenMP build of the same oracle, for the check alone
-            os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, len(os.sched_getaffinity(0)) // max(1, world))))
-            oracle_rate("f32", nx, ny, obstacles, args.accel, 6.0, 8, omp=True, av_out=av_oracle)
-        ok, detail = result_check(good[best]["av"], np.array(av_oracle))
-        out["result_ok"] = ok
-        out["result_check"] = detail
+        if "result_ok" not in out:
+            ok = judge_result()
     if rank == 0:
         print(json.dumps(out), flush=True)
         if not ok:

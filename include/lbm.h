@@ -251,6 +251,13 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  raises the slab's error word and every later wait falls through at once, so the launch sets already
  *                  queued drain at kernel speed; lbm_sync / lbm_download then return LBM_ERR_COMM and the context
  *                  accepts only lbm_destroy
+ *   "push_release" peer transport, producer side: how a pushing wave orders its halo rows before the flag words go up.  1 = release
+ *                  fences at system scope around the ticket (the HSA memory model's guarantee, whatever path the stores took),
+ *                  0 = write-through stores drained with s_waitcnt (measured and soak-tested between slabs and processes on ONE
+ *                  device only), -1 = auto: 1 whenever a ring neighbour lives on another device.  Same results bit for bit.
+ *   "debug_stale_exchange"  TEST HOOK, n >= 1: the n-th halo exchange from now announces itself (flag words, events) but
+ *                  delivers no rows — on every rank of the ring alike —, 0 = off; clears itself when it fires.  Exists so that the
+ *                  checks above the library (bench.py: transport_check) can be shown to catch a transport that loses halo rows.
  *   "compact"      peer transport: -1/1 = one launch per launch set on one stream, its first workgroups — the edge tiles /
  *                  edge chunks — store the halo rows into the neighbours themselves (LDS-tile kernel, three- / four-step
  *                  kernels, deep window kernel); 0 = edge launch / interior launch / push kernel on two streams
@@ -268,6 +275,18 @@ int lbm_copy_bandwidth(size_t bytes, int iters, double *gbps);
  * device issues packed fp32 fused multiply-adds (eight independent chains per thread, eight waves per SIMD), in 1e12
  * lane-instructions per second, over `launches` launches of ~2 ms.  (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3.) */
 int lbm_valu_rate(int launches, double *tera_lane_instr_per_s);
+
+/*
+ * Page-locked host memory for the read-back targets (the reference mallocs them in initialise(), d2q9-bgk.c:519-526,
+ * outside its timed region, and frees them in finalise(), :720-727): device -> host copies of lbm_download and
+ * lbm_final_state into such a buffer run at the PCIe rate (~55 GB/s) instead of the ~20 GB/s a freshly malloc'ed,
+ * never-touched pageable buffer gets (every page faults inside the copy) — SURVEY 8 (f2): "so the reference-rule wall
+ * time is not dominated by I/O".  Optional: every entry point takes any host pointer.  bytes > 0; lbm_host_free(NULL) is
+ * a no-op.  The memory belongs to the caller until lbm_host_free; free it before the process's last lbm_destroy or after,
+ * either order is valid.
+ */
+int lbm_host_alloc(void **ptr_out, size_t bytes);
+int lbm_host_free(void *ptr);
 
 /* Release everything.  Replaces the clRelease* block of finalise (d2q9-bgk.c:729-741). */
 void lbm_destroy(lbm_ctx *ctx);

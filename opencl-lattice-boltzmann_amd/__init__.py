@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "lbm_run_timed", "lbm_sync", "lbm_download", "lbm_steps_done", "lbm_row_range", "lbm_final_state",
     "lbm_reynolds", "lbm_set_option", "lbm_get_option", "lbm_copy_bandwidth", "lbm_valu_rate", "lbm_destroy",
     "lbm_last_error", "lbm_version", "lbm_set_default", "lbm_peer_info_size", "lbm_peer_info", "lbm_connect_peers",
-    "lbm_run_profiled", "lbm_upload_obstacles", "lbm_disconnect_peers",
+    "lbm_run_profiled", "lbm_upload_obstacles", "lbm_disconnect_peers", "lbm_host_alloc", "lbm_host_free",
 ]
 
 TRANSPORTS = {"auto": 0, "rccl": 1, "copy": 2, "peer": 3}
@@ -85,6 +85,8 @@ def load_library():
     L.lbm_peer_info.argtypes = [vp, vp]
     L.lbm_connect_peers.argtypes = [vp, vp, vp]
     L.lbm_disconnect_peers.argtypes = [vp]
+    L.lbm_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
+    L.lbm_host_free.argtypes = [vp]
     L.lbm_destroy.argtypes = [vp]
     L.lbm_destroy.restype = None
     L.lbm_last_error.restype = cp
@@ -181,6 +183,32 @@ def set_default(key, value):
     _check(load_library().lbm_set_default(key.encode(), int(value)), "lbm_set_default(%s)" % key)
 
 
+class HostBuffer:
+    """Page-locked host memory from lbm_host_alloc, seen as a numpy array (`.array`): a read-back target that device -> host
+    copies fill at the PCIe rate.  Free with close() (or leave it to the garbage collector)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.lib = load_library()
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = ctypes.c_void_p()
+        _check(self.lib.lbm_host_alloc(ctypes.byref(self.ptr), nbytes), "lbm_host_alloc")
+        raw = (ctypes.c_char * nbytes).from_address(self.ptr.value)
+        self.array = np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self.lib.lbm_host_free(self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def comm_id():
     """RCCL unique id blob for lbm_create_rank (produce on one rank, broadcast to the others)."""
     L = load_library()
@@ -265,9 +293,14 @@ class LBM:
                                      a.ctypes.data if av_vels else None), "lbm_download")
         return c, (a[:self.steps_done] if av_vels else None)
 
-    def final_state(self):
-        """(u_x, u_y, u, pressure), each float32[ny,nx] — the columns of final_state.dat."""
-        outs = [np.zeros((self.ny, self.nx), dtype=np.float32) for _ in range(4)]
+    def final_state(self, out=None):
+        """(u_x, u_y, u, pressure), each float32[ny,nx] — the columns of final_state.dat.  `out`: a float32[4,ny,nx] array
+        to fill instead of fresh ones (e.g. HostBuffer((4, ny, nx)).array: page-locked)."""
+        if out is not None:
+            assert out.shape == (4, self.ny, self.nx) and out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
+            outs = [out[i] for i in range(4)]
+        else:
+            outs = [np.zeros((self.ny, self.nx), dtype=np.float32) for _ in range(4)]
         _check(self.lib.lbm_final_state(self.ctx, *[o.ctypes.data for o in outs]), "lbm_final_state")
         return outs
 

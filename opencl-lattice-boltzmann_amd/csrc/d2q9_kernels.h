@@ -378,6 +378,7 @@ struct PushArgs {
   uint32_t *flag_lo, *flag_hi;    // the neighbours' flag words for pushes arriving from this side
   uint32_t seq;                   // sequence number of this exchange
   unsigned *ticket;               // workgroups done (reset by the last one)
+  int release;                    // 1: release fences around the ticket (release_pushed), 0: drained write-through stores
 };
 
 __device__ __forceinline__ void flag_store_system(uint32_t *flag, uint32_t v) {
@@ -418,14 +419,35 @@ __device__ __forceinline__ void store4_through_sbase(float *uniform_base, unsign
   store4_through(reinterpret_cast<float *>(reinterpret_cast<char *>(uniform_base) + byte_off), v);
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+// What a pushing wave does between its last write-through store and its arrival at the ticket.  Two forms, chosen per slab
+// by the host (HaloPeer::release, option "push_release"):
+//   formal (1)  a RELEASE FENCE at system scope (buffer_wbl2 sc0 sc1 + s_waitcnt): the pushed rows happen-before the
+//               ticket increment in the sense of the HSA memory model, whatever the cache policy of the mapping they went
+//               through.  The default whenever a ring neighbour lives on another device (xGMI), where nothing but the
+//               model's guarantees has ever been exercised.
+//   drain (0)   s_waitcnt vmcnt(0) only: enough for write-through (sc0 sc1) stores, whose acknowledgement means the data has
+//               left this XCD's L2 — measured and soak-tested between slabs, processes (HIP IPC) on ONE device; it spares the
+//               L2 write-back that the fence also performs for the interior launch's dirty lines.
+__device__ __forceinline__ void release_pushed(int formal) {
+  if (formal) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  else drain_stores();
+}
 
 // The last workgroup of `expected` to arrive publishes the sequence number.  Precondition: every wave of the calling
 // workgroup has drained its write-through stores (drain_stores) before the barrier in here.
-__device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned expected, uint32_t *flag_a, uint32_t *flag_b, uint32_t seq) {
+// `formal`: the publisher joins the arrivals' release fences to the flag stores with an acquire-release fence of its own
+// (ticket read -> acquire, flag store <- release), so that pushed rows -> ticket -> flag is one happens-before chain that
+// ends in the consumer's acquire (halo_wait's fence + the kernel-start acquire of the launch that reads the halo rows).
+__device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned expected, uint32_t *flag_a, uint32_t *flag_b, uint32_t seq,
+                                                  int formal = 0) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == expected - 1) {
+      if (formal) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+        drain_stores();  // (the waitcnt pass drops the fence's own s_waitcnt behind buffer_wbl2 when it sees no store pending)
+      }
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next user starts after this kernel has ended
       if (flag_a) flag_store_system(flag_a, seq);
       if (flag_b) flag_store_system(flag_b, seq);
@@ -440,8 +462,8 @@ static __global__ __launch_bounds__(kBlock) void halo_push(const PushArgs a) {
   float *dst = hi ? a.dst_hi : a.dst_lo;
   const unsigned b = hi ? blockIdx.x - half : blockIdx.x;
   for (size_t i = (size_t)b * kBlock + threadIdx.x; i < a.n4; i += (size_t)half * kBlock) store4_through(dst + 4 * i, src[i]);
-  drain_stores();
-  publish_when_last(a.ticket, gridDim.x, a.flag_lo, a.flag_hi, a.seq);
+  release_pushed(a.release);
+  publish_when_last(a.ticket, gridDim.x, a.flag_lo, a.flag_hi, a.seq, a.release);
 }
 
 // Consumer side: one wave, lanes 0 and 1 poll the two flag words until both have reached `seq`.  The spin is
@@ -461,6 +483,7 @@ struct HaloPeer {
   unsigned long long wait_ticks;
   int push_rows;                   // halo depth H
   int row_lo0, row_hi0;            // stored rows of the first bottom edge row / the first top edge row (the rows that are pushed)
+  int release;                     // how a pushing wave orders its rows before the ticket: see release_pushed
 };
 
 // The kernel's own argument block, re-read where it is used: fields needed only at the very start or the very end of
@@ -496,6 +519,12 @@ __device__ __forceinline__ void spin_on_flags(const uint32_t *flags, uint32_t se
 
 static __global__ void halo_wait(const uint32_t *flags, uint32_t seq, uint32_t *err, unsigned long long timeout) {
   spin_on_flags(flags, seq, err, timeout);
+  // The acquire that pairs with the publisher's release.  What actually makes the halo rows readable is the boundary
+  // behind this kernel: the rows live in THIS device's memory and were written by another agent past this device's
+  // caches, so a reader needs its L1 / L2 copies of those lines dropped — which the kernel-start acquire of the next
+  // launch on the stream does on every XCD that runs it (a fence here reaches only the XCD this one wave runs on;
+  // that is why polling inside the consuming kernel, halo_sync 2, is refused between devices).
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 
@@ -504,6 +533,10 @@ __device__ __forceinline__ void publish_wave_when_last(const HaloPeer *pp, unsig
   if ((threadIdx.x & 63) == 0) {
     const unsigned t = __hip_atomic_fetch_add(pp->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == expected - 1) {
+      if (pp->release) {  // see publish_when_last
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+        drain_stores();
+      }
       __hip_atomic_store(pp->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       flag_store_system(pp->flag_lo, seq);
       flag_store_system(pp->flag_hi, seq);
@@ -623,7 +656,7 @@ __device__ __forceinline__ void push_chunk(const Step2Args *la, int ys, int ye, 
       for (int k = 0; k < 9; k++) store4_through(dst + k * ps, v[k]);
     }
   }
-  drain_stores();
+  release_pushed(__builtin_amdgcn_readfirstlane(pp->release));
 }
 
 struct RowLoads {
@@ -2035,7 +2068,7 @@ __device__ __forceinline__ void push_chunk_pairs(const Step2Args *la, int ys, in
       }
     }
   }
-  drain_stores();
+  release_pushed(__builtin_amdgcn_readfirstlane(pp->release));
 }
 
 // PUSH: the kernel as ONE launch per launch set of a slab (compact launch sets, see Step2Args): the first edge_units
@@ -2393,8 +2426,8 @@ __global__ __launch_bounds__(kMultiThreads) void d2q9_multi(const MultiArgs a) {
         if (lo) store4_through(push_lo + (size_t)orow * a.row_stride + k * ps + gx, v);
         if (hi) store4_through(push_hi + (size_t)(orow - top0) * a.row_stride + k * ps + gx, v);
       }
-      drain_stores();
-      publish_when_last(pp->ticket, (unsigned)edge_blocks, pp->flag_lo, pp->flag_hi, la->seq);
+      release_pushed(pp->release);
+      publish_when_last(pp->ticket, (unsigned)edge_blocks, pp->flag_lo, pp->flag_hi, la->seq, pp->release);
     }
   }
 }

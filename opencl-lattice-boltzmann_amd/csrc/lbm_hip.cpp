@@ -272,6 +272,11 @@ struct lbm_ctx {
   unsigned long long halo_timeout_ms = kHaloWaitMsDefault;  // bound of that spin (option "halo_timeout_ms")
   int compact = -1;         // PEER transport + d2q9_multi: one launch per launch set on ONE stream, the edge tiles push the
                             // halo rows themselves (-1 auto = on, 0 off = edge stream / interior stream / push kernel)
+  int push_release = -1;    // PEER transport, producer side (release_pushed in d2q9_kernels.h): 1 = release fences around the ticket,
+                            // 0 = drained write-through stores, -1 = auto: fences whenever a ring neighbour lives on another device
+  int stale_exchange = 0;   // TEST HOOK (option "debug_stale_exchange"): the n-th halo exchange from now announces itself (flags, events)
+                            // but delivers no rows — what a transport that loses or misplaces halo rows looks like to the checks
+                            // above the library (bench.py transport_check); 0 = off, cleared when it fires
   bool failed = false;      // a run ended in an error after launches had begun: only lbm_destroy is valid
   // lbm_run_profiled: timing events of the first local slab, kProfEvents per launch set, for up to kProfSets sets
   std::vector<hipEvent_t> prof_ev;
@@ -1251,6 +1256,29 @@ struct RcclTransport {
   }
 };
 
+// how a slab's pushing waves order their rows before the ticket (release_pushed): fences between devices unless told otherwise
+int push_release_effective(const lbm_ctx *c, const Slab &s) {
+  if (c->push_release >= 0) return c->push_release;
+  return (s.south.connected && s.south.remote) || (s.north.connected && s.north.remote) ? 1 : 0;
+}
+
+// TEST HOOK "debug_stale_exchange": is the exchange about to be issued the one that delivers nothing?
+bool stale_exchange_now(lbm_ctx *c) { return c->stale_exchange > 0 && --c->stale_exchange == 0; }
+
+// PEER transport: raise the neighbours' flag words to `seq` without moving a row (the stale-exchange test hook of a compact launch set)
+int publish_flags_only(lbm_ctx *c, Slab &s, uint32_t seq, hipStream_t st) {
+  PushArgs a{};
+  a.n4 = 0;
+  a.flag_lo = s.south.flags + 1;
+  a.flag_hi = s.north.flags + 0;
+  a.seq = seq;
+  a.ticket = s.halo_flags + 3;
+  a.release = push_release_effective(c, s);
+  hipLaunchKernelGGL(halo_push, dim3(2), dim3(kBlock), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return LBM_OK;
+}
+
 // PEER transport, consumer side: the launch that follows on `st` reads halo rows that exchange number `seq` fills
 int wait_halos(lbm_ctx *c, Slab &s, hipStream_t st, uint32_t seq) {
   // (halo_sync 2 — the wait inside the consuming kernel — exists for compact launch sets; every other launch is
@@ -1269,6 +1297,7 @@ int wait_halos(lbm_ctx *c, Slab &s, hipStream_t st, uint32_t seq) {
 // rows of their grid `buf`.  Each group of rows is one contiguous block of halo_depth*row_stride floats.
 int exchange_halos(lbm_ctx *c, int buf, int evq, bool on_main = false) {
   const int P = c->nslabs_global;
+  const bool stale = stale_exchange_now(c);
   if (c->transport_eff == TRANSPORT_PEER) {
     const uint32_t seq = c->halo_seq + 1;
     for (Slab &s : c->slabs) {
@@ -1287,6 +1316,8 @@ int exchange_halos(lbm_ctx *c, int buf, int evq, bool on_main = false) {
       a.flag_hi = s.north.flags + 0;
       a.seq = seq;
       a.ticket = s.halo_flags + 3;
+      a.release = push_release_effective(c, s);
+      if (stale) a.n4 = 0;  // (test hook: the flags go up, the rows stay what they were)
       // enough workgroups to move the rows in a few microseconds without taking the chip from the interior launch
       const int per_side = (int)std::max<size_t>(1, std::min<size_t>(64, (a.n4 + 4 * kBlock - 1) / (4 * kBlock)));
       hipLaunchKernelGGL(halo_push, dim3(2 * per_side), dim3(kBlock), 0, on_main ? s.s_main : s.s_edge, a);
@@ -1294,6 +1325,7 @@ int exchange_halos(lbm_ctx *c, int buf, int evq, bool on_main = false) {
     }
     c->halo_seq = seq;
   } else if (c->transport_eff == TRANSPORT_RCCL) {
+    if (stale) return LBM_OK;  // (test hook; every rank of the ring carries the same setting, so nobody waits for a send)
     std::vector<HaloBlock> blocks;
     for (Slab &s : c->slabs) {
       float *g = s.cells[buf];
@@ -1323,6 +1355,7 @@ int exchange_halos(lbm_ctx *c, int buf, int evq, bool on_main = false) {
       Slab &south = c->slabs[(s.index + P - 1) % P];
       HIP_TRY(hipStreamWaitEvent(s.s_edge, south.ev_edgek[evq], 0));
       HIP_TRY(hipStreamWaitEvent(s.s_edge, north.ev_edgek[evq], 0));
+      if (stale) continue;
       HIP_TRY(hipMemcpyAsync(s.cells[buf], south.cells[buf] + (size_t)south.rows * south.row_stride, bytes,
                              hipMemcpyDeviceToDevice, s.s_edge));
       HIP_TRY(hipMemcpyAsync(s.cells[buf] + (size_t)(s.row0 + s.rows) * s.row_stride,
@@ -1449,6 +1482,9 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
     }
     const bool last = (i + adv == nsteps);
     const int q = set & 1, qp = q ^ 1;  // event parity of this launch set / of the previous one
+    // (test hook: a compact launch set whose exchange is the stale one runs without the fused push; a flags-only launch follows it)
+    const bool compact_set = multi && compact && (kind == KIND_MULTI || kind == KIND_FUSED3 || kind == KIND_FUSED4 || kind == KIND_DEEP);
+    const bool stale_set = compact_set && !last && stale_exchange_now(c);
     if (batch_kind != kind || c->ring_fill + adv > c->ring)
       if (int rc = flush()) return rc;
     batch_kind = kind;
@@ -1510,7 +1546,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           a.peer_mode |= 2;
           a.wait_seq = c->halo_seq;
         }
-        if (!last) {
+        if (!last && !stale_set) {
           a.peer_mode |= 1;
           a.peer_buf = src ^ 1;
           a.seq = c->halo_seq + 1;
@@ -1518,6 +1554,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         if (int rc = mark(s, 3, s.s_main)) return rc;
         launch_multi(s, a, m, s.s_main, true);
         HIP_TRY(hipGetLastError());
+        if (stale_set)
+          if (int rc = publish_flags_only(c, s, c->halo_seq + 1, s.s_main)) return rc;
         if (int rc = mark(s, 4, s.s_main)) return rc;
         continue;
       }
@@ -1536,7 +1574,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           a.peer_mode |= 2;
           a.wait_seq = c->halo_seq;
         }
-        if (!last) {
+        if (!last && !stale_set) {
           a.peer_mode |= 1;
           a.peer_buf = src ^ 1;
           a.seq = c->halo_seq + 1;
@@ -1544,6 +1582,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         if (int rc = mark(s, 3, s.s_main)) return rc;
         launch_deep_compact(c, s, a, slot1, adv, s.s_main);
         HIP_TRY(hipGetLastError());
+        if (stale_set)
+          if (int rc = publish_flags_only(c, s, c->halo_seq + 1, s.s_main)) return rc;
         if (int rc = mark(s, 4, s.s_main)) return rc;
         continue;
       }
@@ -1568,7 +1608,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
           a.peer_mode |= 2;
           a.wait_seq = c->halo_seq;
         }
-        if (!last) {
+        if (!last && !stale_set) {
           a.peer_mode |= 1;
           a.peer_buf = src ^ 1;
           a.seq = c->halo_seq + 1;
@@ -1576,6 +1616,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         if (int rc = mark(s, 3, s.s_main)) return rc;
         launch_compact(level, g.paired, a, slot3, slot4, g.units, s.s_main);
         HIP_TRY(hipGetLastError());
+        if (stale_set)
+          if (int rc = publish_flags_only(c, s, c->halo_seq + 1, s.s_main)) return rc;
         if (int rc = mark(s, 4, s.s_main)) return rc;
         continue;
       }
@@ -1689,7 +1731,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (int rc = mark(s, 1, s_edge)) return rc;
       if (int rc = mark(s, 4, s.s_main)) return rc;
     }
-    if (multi && compact && (kind == KIND_MULTI || kind == KIND_FUSED3 || kind == KIND_FUSED4 || kind == KIND_DEEP)) {
+    if (compact_set) {
       if (!last) c->halo_seq++;     // the edge units of this set's launches have pushed exchange number halo_seq
     } else if (multi) {
       if (!last)
@@ -1979,22 +2021,12 @@ int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *whi
     l.flags = (uint32_t *)(uintptr_t)info.flags_ptr;
   } else {
     void *p0 = nullptr, *p1 = nullptr, *pf = nullptr;
-    // (a neighbour's grids are opened by BOTH its ring neighbours at about the same moment — right after the descriptors
-    // have been gathered; an open that fails is tried again a few times before the transport is given up)
-    auto open_retry = [](void **p, hipIpcMemHandle_t h) {
-      hipError_t e = hipSuccess;
-      for (int attempt = 0; attempt < 4; attempt++) {
-        e = hipIpcOpenMemHandle(p, h, hipIpcMemLazyEnablePeerAccess);
-        if (e == hipSuccess) return e;
-        (void)hipGetLastError();
-        *p = nullptr;
-        usleep(20000u << attempt);
-      }
-      return e;
-    };
-    hipError_t e = open_retry(&p0, info.cells[0]);
-    if (e == hipSuccess) e = open_retry(&p1, info.cells[1]);
-    if (e == hipSuccess) e = open_retry(&pf, info.flags);
+    // One attempt each, and the first error is the one reported.  (Round 3 retried a failed open four times on a guess; the
+    // failures it was meant to ride out came from a rank freeing memory its neighbour still had mapped, which the tear-down
+    // order of lbm_disconnect_peers -> barrier -> lbm_destroy removed.  A retry would now only hide a real failure.)
+    hipError_t e = hipIpcOpenMemHandle(&p0, info.cells[0], hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(&p1, info.cells[1], hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf, info.flags, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) {
       if (p0) hipIpcCloseMemHandle(p0);
       if (p1) hipIpcCloseMemHandle(p1);
@@ -2023,6 +2055,7 @@ int connect_link(Slab &s, PeerLink &l, const PeerInfoBlob &info, const char *whi
 // device-side description of a connected slab's neighbours for the fused push / wait of d2q9_multi
 int upload_multi_peer(const lbm_ctx *c, Slab &s) {
   HaloPeer h{};
+  h.release = push_release_effective(c, s);
   for (int b = 0; b < 2; b++) {
     h.push[0][b] = s.south.cells[b] + (size_t)(s.row0 + s.south.rows) * s.row_stride;
     h.push[1][b] = s.north.cells[b];
@@ -2661,6 +2694,21 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     c->halo_sync = (int)value;
     return LBM_OK;
   }
+  if (!strcmp(key, "push_release")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "push_release must be -1 (auto), 0 or 1");
+    if (int rc = sync_all(c)) return rc;
+    c->push_release = (int)value;
+    for (Slab &s : c->slabs)
+      if (s.d_peer && s.south.connected && s.north.connected)
+        if (int rc = upload_multi_peer(c, s)) return rc;
+    return LBM_OK;
+  }
+  if (!strcmp(key, "debug_stale_exchange")) {
+    if (value < 0) return fail(LBM_ERR_ARG, "debug_stale_exchange must be >= 0");
+    if (!c->halo_mode) return fail(LBM_ERR_STATE, "a context without halo rows exchanges nothing");
+    c->stale_exchange = (int)value;
+    return LBM_OK;
+  }
   if (!strcmp(key, "halo_timeout_ms")) {
     if (value < 1 || value > 600000) return fail(LBM_ERR_ARG, "halo_timeout_ms must be 1..600000");
     if (int rc = sync_all(c)) return rc;
@@ -2730,6 +2778,8 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   }
   else if (!strcmp(key, "halo_sync")) *value = c->halo_sync;
   else if (!strcmp(key, "halo_timeout_ms")) *value = (long)c->halo_timeout_ms;
+  else if (!strcmp(key, "push_release")) *value = c->slabs.empty() ? 0 : push_release_effective(c, c->slabs[0]);
+  else if (!strcmp(key, "debug_stale_exchange")) *value = c->stale_exchange;
   else if (!strcmp(key, "compact")) *value = compact_sets(c);
   else if (!strcmp(key, "halo_depth")) *value = c->halo_mode ? c->halo_depth : 0;
   else if (!strcmp(key, "nslabs")) *value = c->nslabs_global;
@@ -2802,6 +2852,19 @@ int lbm_copy_bandwidth(size_t bytes, int iters, double *gbps) {
   hipFree(b);
   if (e != hipSuccess) return fail(LBM_ERR_HIP, "copy kernel: %s", hipGetErrorString(e));
   *gbps = best;
+  return LBM_OK;
+}
+
+int lbm_host_alloc(void **ptr_out, size_t bytes) {
+  if (!ptr_out || bytes == 0) return fail(LBM_ERR_ARG, "lbm_host_alloc: bad argument");
+  *ptr_out = nullptr;
+  HIP_TRY(hipHostMalloc(ptr_out, bytes, hipHostMallocDefault));
+  return LBM_OK;
+}
+
+int lbm_host_free(void *ptr) {
+  if (!ptr) return LBM_OK;
+  HIP_TRY(hipHostFree(ptr));
   return LBM_OK;
 }
 

@@ -453,13 +453,19 @@ int main(int argc, char *argv[])
   int32_t *obstacles = (int32_t *)calloc(ncells, sizeof(int32_t));
   if (obstacles == NULL) die("cannot allocate column memory for obstacles", __LINE__, __FILE__);
   load_obstacles(obstaclefile, &params, obstacles);
-  float *av_vels = (float *)malloc(sizeof(float) * (size_t)(params.max_iters > 0 ? params.max_iters : 1));
-  if (av_vels == NULL) die("cannot allocate memory for av_vels", __LINE__, __FILE__);
 
   int devs[64];
   const int ndev = parse_devices(devs, 64);
   lbm_ctx *ctx = NULL;
   check_lbm(lbm_create(&ctx, &params, obstacles, ndev > 0 ? ndev : 1, ndev > 0 ? devs : NULL), "creating context", __LINE__);
+
+  /* the read-back targets (the reference mallocs them in initialise(), d2q9-bgk.c:519-526,597 — before its timed region):
+   * page-locked, so that the device -> host copies inside the timed region run at the PCIe rate instead of faulting in
+   * every page of a fresh malloc */
+  float *av_vels = NULL, *fields = NULL;
+  check_lbm(lbm_host_alloc((void **)&av_vels, sizeof(float) * (size_t)(params.max_iters > 0 ? params.max_iters : 1)),
+            "allocating memory for av_vels", __LINE__);
+  check_lbm(lbm_host_alloc((void **)&fields, sizeof(float) * 4 * ncells), "allocating memory for output fields", __LINE__);
 
   float *cells = NULL;
   if (getenv("LBM_HOST_INIT")) {
@@ -488,8 +494,6 @@ int main(int argc, char *argv[])
   check_lbm(lbm_download(ctx, NULL, av_vels), "reading av_vels data", __LINE__);
   /* the reference reads the whole 9-plane state back and derives the output columns on the host
    * (d2q9-bgk.c:251-253,787-832); here the device computes the four columns and only those move */
-  float *fields = (float *)malloc(sizeof(float) * 4 * ncells);
-  if (fields == NULL) die("cannot allocate memory for output fields", __LINE__, __FILE__);
   check_lbm(lbm_final_state(ctx, fields, fields + ncells, fields + 2 * ncells, fields + 3 * ncells),
             "reading cells data", __LINE__);
   float reynolds = 0.0f;
@@ -522,9 +526,9 @@ int main(int argc, char *argv[])
 
   /* finalise (d2q9-bgk.c:715-744) */
   lbm_destroy(ctx);
-  free(fields);
+  lbm_host_free(fields);
+  lbm_host_free(av_vels);
   free(cells);
   free(obstacles);
-  free(av_vels);
   return EXIT_SUCCESS;
 }

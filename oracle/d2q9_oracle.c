@@ -231,8 +231,16 @@ REAL oracle_timestep(const oracle_params *p, const REAL *src, REAL *dst, const i
 
 double oracle_timestep_rows(const oracle_params *p, const REAL *src, REAL *dst, const int *obstacles, int y0, int y1)
 {
+  if (y1 <= y0) return 0.0;
+  /* per-row sums added up in row order, as in oracle_timestep: the same value with and without OpenMP */
+  double *row_sums = (double *)malloc(sizeof(double) * (size_t)(y1 - y0));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int ii = y0; ii < y1; ii++) row_sums[ii - y0] = timestep_row(p, src, dst, obstacles, ii);
   double tot_u = 0.0;
-  for (int ii = y0; ii < y1; ii++) tot_u += timestep_row(p, src, dst, obstacles, ii);
+  for (int ii = y0; ii < y1; ii++) tot_u += row_sums[ii - y0];
+  free(row_sums);
   return tot_u;
 }
 

@@ -64,6 +64,8 @@ int lbm_run(lbm_ctx *c, int n)
 int lbm_run_timed(lbm_ctx *c, int n, double *ms) { if (ms) *ms = 1.0; return lbm_run(c, n); }
 int lbm_run_profiled(lbm_ctx *c, int n, double *st) { memset(st, 0, 8 * sizeof(double)); return lbm_run(c, n); }
 int lbm_sync(lbm_ctx *c) { (void)c; return LBM_OK; }
+int lbm_host_alloc(void **p, size_t bytes) { if (!p || !bytes) return LBM_ERR_ARG; *p = malloc(bytes); return *p ? LBM_OK : LBM_ERR_HIP; }
+int lbm_host_free(void *p) { free(p); return LBM_OK; }
 int lbm_steps_done(const lbm_ctx *c) { return c ? c->steps : -1; }
 int lbm_row_range(const lbm_ctx *c, int *y0, int *y1) { if (y0) *y0 = 0; if (y1) *y1 = c->p.ny; return LBM_OK; }
 int lbm_download(lbm_ctx *c, float *cells, float *av)

@@ -549,21 +549,55 @@ def test_8192x8192_cavity_over_8_slabs_equals_one_slab(lbm):
     assert max_rel(av_many, av_one) < 2e-6
 
 
-def test_c_host_end_to_end(tmp_path):
-    """the drop-in: ./d2q9-bgk <params> <obstacles> -> files -> check.py, as `make check` does"""
+def run_check_cli(tmp_path, size):
+    """check/check.py as a program (the reference's `make check`, Makefile:26-27) on the files in tmp_path"""
+    import sys
+    ref_av = golden_path("%s.av_vels.dat" % size, tmp_path)
+    if size in ("128x128", "128x256"):
+        ref_fs = golden_path("%s.final_state.dat" % size, tmp_path)
+    else:  # the reference repository lacks these two files; regenerated with the pinned fp64 oracle
+        ref_fs = generated_final_state(size, str(tmp_path / ("ref_%s.final_state.dat" % size)))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "check", "check.py"),
+                           "--ref-av-vels-file=" + ref_av, "--ref-final-state-file=" + ref_fs,
+                           "--av-vels-file=" + str(tmp_path / "av_vels.dat"),
+                           "--final-state-file=" + str(tmp_path / "final_state.dat")], capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("size", SIZES)
+def test_c_host_acceptance_all_shipped_inputs(tmp_path, size):
+    """north_star's acceptance gate through the DROP-IN itself: ./d2q9-bgk.exe <params> <obstacles> (full length) ->
+    final_state.dat + av_vels.dat -> check/check.py as a program, for each of the four shipped inputs; 1024x1024 a second
+    time row-partitioned over four slabs (LBM_DEVICES=0,0,0,0: the multi-GPU data path on one GPU), byte-identical
+    final state"""
     exe = os.path.join(ROOT, "d2q9-bgk.exe")
-    r = subprocess.run([exe, *input_files("128x128")], cwd=tmp_path, capture_output=True, text=True)
+    r = subprocess.run([exe, *input_files(size)], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for label in ("==done==", "Reynolds number:\t\t", "Elapsed time:\t\t\t", "Elapsed user CPU time:\t\t",
                   "Elapsed system CPU time:\t"):
         assert label in r.stdout
-    import sys
-    c = subprocess.run([sys.executable, os.path.join(ROOT, "check", "check.py"),
-                        "--ref-av-vels-file=" + golden_path("128x128.av_vels.dat", tmp_path),
-                        "--ref-final-state-file=" + golden_path("128x128.final_state.dat", tmp_path),
-                        "--av-vels-file=" + str(tmp_path / "av_vels.dat"),
-                        "--final-state-file=" + str(tmp_path / "final_state.dat")], capture_output=True, text=True)
-    assert c.returncode == 0 and "Both tests passed!" in c.stdout, c.stdout
+    c = run_check_cli(tmp_path, size)
+    assert c.returncode == 0 and "Both tests passed!" in c.stdout, c.stdout + c.stderr
+    nx, ny = (int(v) for v in size.split("x"))
+    first = open(tmp_path / "final_state.dat", "rb").read()
+    assert first.count(b"\n") == nx * ny
+    ref_re = {"128x128": 9.763598020526, "128x256": 37.18483826704, "256x256": 10.07703420252,
+              "1024x1024": 3.377417654904}[size]
+    got_re = float([ln for ln in r.stdout.splitlines() if ln.startswith("Reynolds number:")][0].split()[2])
+    assert abs(got_re / ref_re - 1.0) < 5e-3
+    if size == "1024x1024":
+        env = dict(os.environ, LBM_DEVICES="0,0,0,0")
+        r = subprocess.run([exe, *input_files(size)], cwd=tmp_path, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert open(tmp_path / "final_state.dat", "rb").read() == first     # same per-cell arithmetic on every slab
+        c = run_check_cli(tmp_path, size)
+        assert c.returncode == 0 and "Both tests passed!" in c.stdout, c.stdout + c.stderr
+
+
+def test_c_host_writer_and_slab_environment(tmp_path):
+    """the host's output writer (line format, thread count) and its LBM_DEVICES / LBM_NGPUS environment"""
+    exe = os.path.join(ROOT, "d2q9-bgk.exe")
+    r = subprocess.run([exe, *input_files("128x128")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
     # the multi-threaded writer produces the same bytes as a single thread, in the reference's line format
     first = open(tmp_path / "final_state.dat", "rb").read()
     import re
@@ -578,6 +612,15 @@ def test_c_host_end_to_end(tmp_path):
     r = subprocess.run([exe, *input_files("128x128")], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert open(tmp_path / "final_state.dat", "rb").read() == first
+    # LBM_NGPUS=N asks for devices 0..N-1: on a one-GPU box that must fail with the library's message, not crash
+    env = dict(os.environ, LBM_NGPUS="2")
+    env.pop("LBM_DEVICES", None)
+    r = subprocess.run([exe, *input_files("128x128")], cwd=tmp_path, capture_output=True, text=True, env=env)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 1 and "device index 1 out of range" in r.stderr, r.stderr
+    else:
+        assert r.returncode == 0 and open(tmp_path / "final_state.dat", "rb").read() == first
 
 
 # ---- full benchmark size: properties that need no full-size oracle run ------------------------------------

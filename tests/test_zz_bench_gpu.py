@@ -19,6 +19,40 @@ def _bench_failure(r):
     return "exit code %d\nstderr:\n%s\nstdout tail:\n%s" % (r.returncode, "\n".join(err[-60:]), r.stdout[-600:])
 
 
+def _records(r, rank_mode):
+    """the record lines of a run: ONE on a single GPU; with ranks the headline record (`partial`) and then the full one"""
+    import json
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not rank_mode:
+        assert len(lines) == 1
+        return lines[0]
+    assert len(lines) == 2 and "partial" in lines[0] and "partial" not in lines[1]
+    head, full = lines
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "result_ok", "transport_check"):
+        assert key in head and head[key] == full[key], key     # the early record is the full record minus the side legs
+    assert "also" not in head and "weak" not in head
+    return full
+
+
+def _checked(tc, transports):
+    """transport_check of a clean run: every transport through all three legs"""
+    assert tc["fault_injected"] is None and set(tc["legs"]) == {"small", "deep", "digest"}
+    for t in transports:
+        assert tc["transports"][t]["ok"] and tc["transports"][t]["failed_legs"] == []
+        small, deep, dig = (tc["legs"][k]["transports"][t] for k in ("small", "deep", "digest"))
+        assert small["ok"] and small["cells_max_rel"] < 2e-5 and small["av_vels_max_rel"] < 1e-4 and small["exchanges"] >= 50
+        assert deep["ok"] and deep["cells_max_rel"] < 2e-5 and deep["av_vels_max_rel"] < 1e-4
+        assert deep["halo_depth"] == 8 and deep["exchanges"] == 5 and deep["kernel"].startswith("d2q9_deep")
+        assert dig["ok"] and len(dig["digest_rank0"]) == 32
+    # the deep leg ran the kernels the 8192x8192 leg of a multi-GPU run runs: chunk pairs with the in-kernel push over peer
+    # stores, the lone kernel on two streams over RCCL
+    if "peer" in transports:
+        assert tc["legs"]["deep"]["transports"]["peer"]["kernel"] == "d2q9_deep_twin, compact launch sets"
+    if "rccl" in transports:
+        assert tc["legs"]["deep"]["transports"]["rccl"]["kernel"] == "d2q9_deep, two streams"
+
+
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline` (small grid here)"""
     import json
@@ -79,13 +113,11 @@ def test_bench_starts_its_own_ranks():
                         "--warmup", "12", "--nx", "2048", "--ny", "1024", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, _bench_failure(r)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    j = _records(r, True)
     assert j["n_gpus"] == 1 and j["result_ok"] is True and j["launcher"].startswith("torch.distributed.run started by bench.py")
     assert set(j["transports"]) == {"peer", "rccl"} and j["rccl_world_size"] == 1
-    tc = j["transport_check"]["transports"]
-    assert tc["rccl"]["ok"] and tc["peer"]["ok"] and tc["peer"]["cells_max_rel"] < 2e-5 and tc["rccl"]["av_vels_max_rel"] < 1e-4
+    _checked(j["transport_check"], ["peer", "rccl"])
+    assert j["transport_check"]["legs"]["digest"]["compared_with"] == "each other"     # peer and RCCL, bit for bit
     assert j["also"]["value"] > 1000 and j["weak"]["scaling"] == "weak" and j["weak"]["value"] > 1000
     assert j["weak"]["per_gpu"] == j["weak"]["value"] and len(j["weak"]["per_rank_launch_set_us"]) == 1
 
@@ -105,14 +137,13 @@ def test_bench_rehearsal_of_the_multi_rank_path(nranks):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "24", "--warmup", "8",
                         "--nx", "2048", "--ny", "1024", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, _bench_failure(r)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    j = _records(r, True)
     assert j["n_gpus"] == nranks and j["result_ok"] is True and "NOT a benchmark" in j["rehearsal"]
     assert j["config"]["partition"] == "rows x%d" % nranks and abs(j["config"]["rows_per_gpu"] - 1024 / nranks) < 1
     assert set(j["transports"]) == {"peer"} and j["transport"] == "peer" and j["rccl_world_size"] == 0
-    tc = j["transport_check"]["transports"]["peer"]
-    assert tc["ok"] and tc["cells_max_rel"] < 2e-5 and tc["av_vels_max_rel"] < 1e-4
+    _checked(j["transport_check"], ["peer"])
+    assert j["transport_check"]["legs"]["digest"]["compared_with"] == "undivided grid"
+    assert "8192x%d" % (768 * nranks) in j["transport_check"]["legs"]["deep"]["workload"]
     assert j["result_check"]["compared_steps"] >= 3 and j["result_check"]["av_vels_max_rel_vs_oracle"] < 1e-4
     pr = j["per_rank_launch_set_us"]
     assert [p["rank"] for p in pr] == list(range(nranks)) and all(p["transport"] == "peer" and p["sets"] >= 1 for p in pr)
@@ -120,6 +151,34 @@ def test_bench_rehearsal_of_the_multi_rank_path(nranks):
     assert j["also"]["value"] > 100 and len(j["also"]["per_rank_launch_set_us"]) == nranks
     assert j["weak"]["scaling"] == "weak" and j["weak"]["workload"].startswith("2048x%d" % (1024 * nranks)) and j["weak"]["value"] > 100
     assert j["value_cold"] > 100
+
+
+@pytest.mark.parametrize("legs", ["deep", "small,digest"])
+def test_bench_transport_check_catches_a_stale_halo(legs):
+    """the checks have teeth: with ONE halo exchange of the named check legs delivering nothing (library test hook
+    debug_stale_exchange: the flag words go up, the rows stay what they were — what a transport that loses halo rows over xGMI
+    would look like) the transport fails exactly those legs, is neither timed nor reported, and the run ends with exit code 1
+    and an error record"""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LBM_BENCH_RANK_MODE", "LBM_BENCH_CHILD")}
+    env["LBM_BENCH_REHEARSAL"] = "1"
+    env["LBM_BENCH_FAULT"] = "stale_halo@" + legs
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8",
+                        "--nx", "2048", "--ny", "1024", "--no-cpu-baseline", "--no-cold"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, _bench_failure(r)
+    j = lines[0]
+    assert j["value"] is None and j["result_ok"] is False and "no halo transport passed" in j["error"]
+    tc = j["transport_check"]
+    assert tc["fault_injected"] == sorted(legs.split(",")) and tc["transports"]["peer"]["ok"] is False
+    assert sorted(tc["transports"]["peer"]["failed_legs"]) == sorted(legs.split(","))
+    for leg in ("small", "deep"):
+        t = tc["legs"][leg]["transports"]["peer"]
+        assert t["ok"] == (leg not in legs) and (t["cells_max_rel"] > 1e-3) == (leg in legs)    # stale rows: errors of the noise's size
+    d = tc["legs"]["digest"]["transports"]["peer"]
+    assert d["ok"] == ("digest" not in legs) and (("ranks_that_differ" in d) == ("digest" in legs))
 
 
 def test_bench_one_process_form_rehearsal():
@@ -154,9 +213,7 @@ def test_bench_one_process_per_gpu_path_single_rank():
                         "--gpus", "1", "--steps", "60", "--warmup", "12", "--nx", "2048", "--ny", "1024",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, _bench_failure(r)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    j = _records(r, True)
     assert j["n_gpus"] == 1 and j["result_ok"] is True and j["value"] > 1000
     assert j["roofline"]["steps_per_launch"] == 4   # 2048x1024 = 2M cells: four steps per launch, also with halo rows
     # both halo transports were measured on the ring of one; per-rank launch-set timings explain the record
@@ -169,5 +226,5 @@ def test_bench_one_process_per_gpu_path_single_rank():
     assert j["also"]["value"] > 1000 and j["also"]["halo_depth"] >= 3 and len(j["also"]["per_rank_launch_set_us"]) == 1
     # before any timing every transport reproduced the oracle on the 1024x1024 obstacles from a random state (a transport
     # delivering stale or misplaced halo rows would not), and the weak-scaling leg of config 5 is in the same line
-    assert all(t["ok"] for t in j["transport_check"]["transports"].values())
+    _checked(j["transport_check"], ["peer", "rccl"])
     assert j["weak"]["value"] > 1000 and j["launcher"].startswith("external")

@@ -104,6 +104,8 @@ if fk is not None and "traffic_bytes" in ev and len(sys.argv) > 6 and sys.argv[6
             version = json.loads(ln).get("library")
     tj["%dx%d/%s" % (nx, ny, "deep_twin" if "deep_twin" in kern else "deep" if "deep" in kern else "step%d" % per_launch)] = {
         "hbm_bytes_per_launch": ev["traffic_bytes"], "fetch_size_kib": fk, "write_size_kib": wk, "library_version": version,
+        # the launches these bytes were counted on: bench.py prices `traffic_frac` on THEIR duration, not on the run's own
+        "steps_per_launch": per_launch, "launch_us": round(stats["avg_ns"] / 1e3, 2),
         "source": "profiles/%s.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of the same bench.py command on %s, FETCH doubled per "
                   "MI355X_MICROARCH.md and checked on a 1 GiB copy)" % (tag, datetime.date.today()),
         "evidence": {k: v for k, v in ev.items() if k != "traffic_bytes"}}
