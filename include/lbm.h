@@ -203,7 +203,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  at most that many timesteps per launch: a run is cut into the fewest launches, of equal depth
  *                  (20 steps = 7 + 7 + 6); with row slabs capped by the halo depth (8 for slabs of 3M cells and more);
  *                  falls back to 4 on grids under 32 rows per slab.  0 = one launch per step, -1 = auto (by size: 8
- *                  from 3M cells per slab; one slab without halo rows: above 300K cells, always as chunk pairs).
+ *                  from 3M cells per slab; one slab without halo rows: above 300K cells, always as chunk pairs).  5 = the
+ *                  chunk pairs at five steps per launch set on row slabs that carry five halo rows (slabs of 240K to 3M cells)
+ *                  in compact launch sets — what auto chooses there; the four-step kernel anywhere else.
  *   "twin_steps"   chunk-pair form of the deep window kernel ("pair"): most timesteps per launch, 2..8, 0 = auto (5 below
  *                  3M cells, 8 from there on)
  *   "steady"       deep window kernel: -1/1 = a launch of exactly 5 (chunk pairs below 3M cells), 6, 7 or 8 timesteps runs the

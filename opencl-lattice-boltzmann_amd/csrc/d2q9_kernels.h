@@ -2155,14 +2155,19 @@ __global__ __launch_bounds__(64, 2) void d2q9_deep(const Step2Args a, float *par
 // workgroups are the EDGE workgroups — wave 0 works on the bottom edge rows, wave 1 on the top edge rows of one strip (chunks 0
 // and 2 of the edge table {bottom edge, (interior), top edge}); neither has a twin, both run alone, push their rows into
 // the ring neighbours, and the last edge wave raises the flag words —, the others are the interior's chunk pairs.
+// PUSH with D <= 5 (slabs of 240K to 3M cells, five halo rows): the edge rows of such a slab are as long a sweep as an interior
+// chunk is (2-5 rows), so a lone edge wave — H + 2(D-1) = 13 iterations against the pairs' ~7 — would be what the launch waits
+// for.  Here the H rows at either end are a chunk PAIR of their own (edge table {b0, b1, b2 | interior | t0 (empty), t0, t1, t2}:
+// chunks 0/1 and 4/5; the first 2 x strips workgroups), twinned like any other; every edge wave pushes its own rows.
 template <int D, bool NT, bool OBST_PATHS = false, int LT = 0, bool PUSH = false>
 __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, float *partials, int pstride, int nlev) {
   constexpr int WL = deep_lds_windows(D), HL = deep_halo_lanes(D);
   constexpr int kWaveFloats = WL * kPairWinFloats + (D - 1 > WL ? 3 * kPairSlotFloats : 0) + 4;
+  constexpr bool EDGE_PAIRS = PUSH && D <= 5;
   __shared__ float lds[2 * kWaveFloats];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const UnitSel us = select_unit<PUSH>(a, a.edge_units / 2);
+  const UnitSel us = select_unit<PUSH>(a, a.edge_units / 2);  // edge_units counts edge WAVES
   const bool do_push = PUSH && us.edge && (a.peer_mode & 1);
   if constexpr (PUSH) {
     // in-kernel wait for the neighbours' halo rows (halo_sync = 2): every edge wave for itself, before its first load
@@ -2179,8 +2184,8 @@ __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, floa
   const int sdiv = edge_wg ? a.strips_edge : a.strips;
   const int pair = punit / sdiv;
   int strip = punit - pair * sdiv;
-  const int chunk = edge_wg ? 2 * wv : 2 * pair + wv;
-  const int unit = chunk * sdiv + strip + us.partial_off;
+  const int chunk = edge_wg ? (EDGE_PAIRS ? 4 * pair + wv : 2 * wv) : 2 * pair + wv;
+  const int unit = ((edge_wg && EDGE_PAIRS) ? 2 * pair + wv : chunk) * sdiv + strip + us.partial_off;  // (edge pairs: four slots per strip)
   int ys, ye, pys, pye;
   if (a.vmap != nullptr && !edge_wg) {  // (virtual strips, see Step2Args: a copy's chunks 2p / 2p+1 are the halves of one chunk)
     const int *e = a.vtab + 2 * ((size_t)a.vmap[2 * strip + 1] * a.nchunks + chunk), *pe = e + (wv ? -2 : 2);
@@ -2192,8 +2197,8 @@ __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, floa
     pys = us.chunk_start[chunk ^ 1]; pye = us.chunk_start[(chunk ^ 1) + 1];
   }
   const bool empty = ys >= ye || (!(PUSH && us.edge) && chunk == us.skip);
-  const bool twinned = !(PUSH && us.edge) && !empty && pys < pye && (chunk ^ 1) != us.skip;  // the same on both waves
-  if constexpr (PUSH) {
+  const bool twinned = !(PUSH && us.edge && !EDGE_PAIRS) && !empty && pys < pye && (chunk ^ 1) != us.skip;  // the same on both waves
+  if constexpr (PUSH && !EDGE_PAIRS) {
     // nobody works on the edge table's middle chunk (the interior): its slot of the velocity sums is this wave's to clear
     if (us.edge && wv == 0 && lane < nlev) partials[(size_t)lane * pstride + (a.strips_edge + strip + us.partial_off)] = 0.f;
   }

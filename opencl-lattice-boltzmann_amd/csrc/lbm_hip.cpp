@@ -388,9 +388,27 @@ constexpr long kTwinDeepCells = 3L << 20;
 // r03_scaling_projection.txt): 2048x1024 and 4096x512 (2M cells) 176 / 161 and 172 / 167; 2048x2048, 4096x1024, 8192x512
 // (4M) 209 / 244, 210 / 245, 201 / 238 -> from 3M cells (round 2, before the per-depth kernels: 5M).
 constexpr long kSlabDeepCells = 3L << 20;
+// Row slabs between these sizes carry FIVE halo rows and, in compact launch sets (peer stores), run the chunk pairs of the
+// mid-size grids — d2q9_deep_twin<5, ..., PUSH>, five steps per launch set — instead of the LDS tiles (up to 540K cells) and
+// the three- / four-step kernels (up to 3M): one GPU ran the 1024x1024 input at 5.7 us/step with the pairs while a 1024x512
+// slab of it took 7.3 (two GPUs slower than one).  Launch sets on two streams (RCCL, copies) keep those kernels,
+// with the halo rows they always had up to 540K cells (eight: the LDS tiles, eight steps per exchange — the pairs then use the five
+// nearest of the eight stored rows) and with five above (the three- / four-step kernels exchange five rows per set instead of 3 / 4).
+// Ring of one over peer stores, us/step, previous choice -> pairs (profiles/r04_slab_twin5.txt): 1024x512 7.34 -> 4.87, 2048x512
+// 9.03 -> 6.18, 1024x1024 8.75 -> 6.16, 2048x1024 11.89 -> 9.72, 4096x512 12.18 -> 9.62, 8192x256 12.08 -> 9.92, 2048x1400 14.57 ->
+// 12.37; NOT 1024x256 (262K cells): LDS tiles 4.10, pairs 5.00 -> from 300K cells, as on one slab without halo rows.
+constexpr long kSlabTwinCells = 300L * 1024;
 constexpr int kOneRoundRows = 160;   // d2q9_deep: longest chunk of a one-round schedule (see deep_geometry)
 constexpr int kMaxHeavyStrips = 4;  // see build_clean_bits / balance_heavy_strips
+bool compact_transport(const lbm_ctx *c) { return c->halo_mode && c->transport_eff == TRANSPORT_PEER && c->compact != 0; }
+// the slab form of the five-step chunk pairs (see kSlabTwinCells): five halo rows, compact launch sets, kernel choice left to the library
+bool slab_twin5(const lbm_ctx *c) {
+  if ((long)c->p.nx * c->rows_min <= kSlabTwinCells || (long)c->p.nx * c->rows_min >= kSlabDeepCells) return false;
+  return compact_transport(c) && (c->halo_depth == kDeepTwinDefault || c->halo_depth == kMultiMaxT) && fuse_possible(c) && c->rows_min >= 4 * kDeepTwinDefault &&
+         c->pair != 0 && c->multistep <= 0 && (c->fuse < 0 || c->fuse == kDeepTwinDefault) && c->twin_steps <= 0;
+}
 int twin_cap(const lbm_ctx *c) {
+  if (slab_twin5(c)) return kDeepTwinDefault;
   if (c->twin_steps > 0) return c->twin_steps;
   return (long)c->p.nx * c->rows_min >= kTwinDeepCells ? kDeepTwinSteps : kDeepTwinDefault;
 }
@@ -402,6 +420,7 @@ bool deep_twin_effective(const lbm_ctx *c) {
 // where the halo rows are fewer than 3)
 int fuse_level(const lbm_ctx *c) {
   if (!fuse_possible(c)) return 0;
+  if (slab_twin5(c)) return kDeepTwinDefault;
   int lvl;
   if (c->fuse >= 0) {
     lvl = c->fuse == 0 ? 0 : (c->fuse >= 3 ? c->fuse : 2);
@@ -439,9 +458,11 @@ bool fuse_effective(const lbm_ctx *c) { return fuse_level(c) != 0; }
 int multistep_effective(const lbm_ctx *c) {
   // launch grids stay small (tile count from the smallest tile and the largest slab: identical on every rank)
   if ((long)div_up(c->p.nx, 16) * div_up(c->rows_min + 1, 8) > 65536) return 0;
+  if (slab_twin5(c)) return 0;
   // with halo rows a launch can advance at most as many steps as the halos are deep
   const int cap = c->halo_mode ? std::min(kMultiMaxT, c->halo_depth) : kMultiMaxT;
-  if (c->halo_mode && c->halo_depth < kMultiMaxT && c->multistep < 0) return 0;  // big slabs: the register/LDS-window kernels
+  // big slabs: the register/LDS-window kernels
+  if (c->halo_mode && c->halo_depth < kMultiMaxT && c->multistep < 0) return 0;
   if (c->multistep >= 0) return std::min(c->multistep, cap);
   // auto (profiles/r01_kernel_choice.txt, us/step LDS tiles / two-step kernel): 128x128 1.4 / 5, 384x384 3.4 / 4.2,
   // 512x512 3.9 / 4.4, 768x512 5.6 / 4.5, 1024x512 7.3 / 6.4 -> up to 300K cells on one slab.  Slabs that exchange
@@ -455,7 +476,8 @@ int multistep_effective(const lbm_ctx *c) {
 // of edge launch + push kernel on an edge stream beside the interior launch.  For the LDS-tile kernel and for the
 // three- / four-step kernels in their default form (LDS windows, one row-set of loads in flight, plain loads).
 bool compact_sets(const lbm_ctx *c) {
-  if (!c->halo_mode || c->transport_eff != TRANSPORT_PEER || c->compact == 0) return false;
+  if (!compact_transport(c)) return false;
+  if (slab_twin5(c)) return true;    // d2q9_deep_twin<5, .., PUSH>
   if (multistep_effective(c) > 0) return true;
   const int lvl = fuse_level(c);
   if (lvl >= kDeepMin) return true;  // d2q9_deep<.., PUSH>
@@ -664,9 +686,11 @@ const unsigned long long *clean_bits_for(const lbm_ctx *c, const Slab &s, const 
 
 // Schedules of d2q9_deep for a slab: lanes of two cells, deep_halo_lanes() of them idle at either end of a strip; strips
 // start on 64-byte boundaries (8 lanes).  2*(D-1) redundant start-up iterations per chunk -> long chunks.
+int twin5_slab_geometry(const lbm_ctx *c, Slab &s);
 int deep_geometry(const lbm_ctx *c, Slab &s) {
   s.f6_main.units = s.f6_edge.units = s.f6_twin.units = 0;
   s.f6_twin.paired = false;
+  if (slab_twin5(c)) return twin5_slab_geometry(c, s);
   if (!deep_possible(c)) return LBM_OK;
   const int q2 = c->p.nx / 2, lmax = 64 - 2 * lbm::deep_halo_lanes(kDeepSteps);
   s.strips2 = div_up(q2, lmax / 8 * 8);
@@ -827,6 +851,39 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     }
   }
   s.nb_total = std::max(s.nb_total, s.f6_main.units + e.units);
+  return LBM_OK;
+}
+
+// Compact launch sets of d2q9_deep_twin<5, ..., PUSH> (slab_twin5): strips of up to 60 lanes of two cells as on one slab; the
+// five rows at either end of the slab are a chunk pair each (edge table {b0, b1, b2 | interior | t0, t0, t1, t2}: chunks 0/1 and
+// 4/5, chunk 2 = the interior, chunk 3 empty — see the kernel), the interior one round of chunk pairs on the wave slots
+// the 2 x strips edge workgroups leave.
+int twin5_slab_geometry(const lbm_ctx *c, Slab &s) {
+  const int q2 = c->p.nx / 2, lmax5 = 64 - 2 * lbm::deep_halo_lanes(kDeepTwinDefault);
+  s.strips_tw = div_up(q2, lmax5 / 4 * 4);
+  s.lanes_tw = std::min(lmax5, (div_up(q2, s.strips_tw) + 3) / 4 * 4);
+  free_balance(s.f6_main);
+  free_balance(s.f6_twin);
+  FuseGeom &e = s.f6_edge;
+  const int H = kDeepTwinDefault, b0 = s.row0, t0 = s.row0 + s.rows - H;  // (the five nearest of the stored halo rows: 5 or 8 of them)
+  const int tab[7] = {b0, b0 + H / 2, b0 + H, t0, t0, t0 + H - H / 2, t0 + H};
+  if (set_dev(s)) return LBM_ERR_HIP;
+  if (e.chunk_start) HIP_TRY(hipFree(e.chunk_start));
+  e.chunk_start = nullptr;
+  if (dev_alloc(&e.chunk_start, 7)) return LBM_ERR_HIP;
+  HIP_TRY(hipMemcpy(e.chunk_start, tab, sizeof(tab), hipMemcpyHostToDevice));
+  e.nchunks = 6;
+  e.skip = 2;
+  e.nbands = 1;
+  e.units_per_band = e.units = 4 * s.strips_tw;  // edge WAVES: one slot of the velocity sums each
+  FuseGeom &g = s.f6_main;
+  g.paired = true;
+  if (tab[3] > tab[2]) {
+    const int c6max = std::max(8, std::min(c->chunk_rows > 0 ? c->chunk_rows : 96, s.rows));
+    const int c6min = std::max(4, std::min(c->chunk_min > 0 ? c->chunk_min : 24, c6max));
+    if (int rc = fuse_schedule(s, tab[2], tab[3], c6max, c6min, true, g, 2, e.units, true, s.strips_tw)) return rc;
+  }
+  s.nb_total = std::max(s.nb_total, g.units + e.units);
   return LBM_OK;
 }
 
@@ -1126,6 +1183,27 @@ void launch_deep_compact(const lbm_ctx *c, const Slab &s, const Step2Args &a0, f
   a.clean_bits = clean_bits_for(c, s, s.f6_main);
   a.clean_words = s.clean_words;
   const bool nt = nt_effective(c), paths = c->obst_paths != 0;
+  if (slab_twin5(c)) {
+    // five halo rows: interior chunk pairs + two edge chunk pairs per strip, d2q9_deep_twin<5, ..., PUSH> (twin5_slab_geometry)
+    a.strips = a.strips_edge = s.strips_tw;
+    a.lanes_out = s.lanes_tw;
+    a.clean_bits = nullptr;
+    a.units_per_band = a0.units_per_band / 2;  // chunk pairs x strips
+    a.edge_units = 4 * s.strips_tw;            // edge WAVES
+    const dim3 pgrid(2 * s.strips_tw + s.f6_main.units / 2), pblock(128);
+    constexpr int D5 = kDeepTwinDefault;
+    if (paths && c->steady != 0 && nlev == D5) {
+      if (nt) hipLaunchKernelGGL((d2q9_deep_twin<D5, true, true, D5, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+      else hipLaunchKernelGGL((d2q9_deep_twin<D5, false, true, D5, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    } else if (paths) {
+      if (nt) hipLaunchKernelGGL((d2q9_deep_twin<D5, true, true, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+      else hipLaunchKernelGGL((d2q9_deep_twin<D5, false, true, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    } else {
+      if (nt) hipLaunchKernelGGL((d2q9_deep_twin<D5, true, false, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+      else hipLaunchKernelGGL((d2q9_deep_twin<D5, false, false, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    }
+    return;
+  }
   if (s.f6_main.paired) {
     // interior chunk pairs + one edge workgroup per strip (bottom and top edge rows on its two waves): d2q9_deep_twin<..., PUSH>
     a.units_per_band = a0.units_per_band / 2;     // chunk pairs x strips
@@ -1417,6 +1495,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
     }
 
   // d2q9_deep as chunk pairs: one slab without halo rows whose pair schedule is one round of units (all slabs alike)
+  const bool deep_lvl = fuse_lvl >= kDeepMin || slab_twin5(c);  // the deep window kernels (slab_twin5: their five-step pairs in compact launch sets)
   const bool deep_twin = fuse_lvl >= kDeepMin && deep_twin_effective(c);
   int batch_first = c->steps_done;
   enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4, KIND_FUSED4 = 5, KIND_DEEP = 6 };
@@ -1464,7 +1543,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
     if (multi_T > 0) {
       kind = KIND_MULTI;
       adv = std::min(multi_T, nsteps - i);
-    } else if (fuse_lvl >= kDeepMin && nsteps - i >= 2) {
+    } else if (deep_lvl && nsteps - i >= 2) {
       // the remaining steps in as few launches as possible, of equal depth (every launch moves the whole grid once:
       // 20 steps = 7+7+6, not 8+8+4)
       kind = KIND_DEEP;
@@ -1938,12 +2017,16 @@ int alloc_partials(lbm_ctx *c) {
   return LBM_OK;
 }
 
+int upload_multi_peer(const lbm_ctx *c, Slab &s);
 int rebuild_geometry(lbm_ctx *c) {
   // grid_blocks / chunk changes alter the number of partial sums per step
   for (Slab &s : c->slabs) {
     if (set_dev(s)) return LBM_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(s.s_main));
     if (int rc = slab_geometry(c, s)) return rc;
+    // (which rows the pushing kernels store where depends on the kernel the options select: slab_twin5)
+    if (s.d_peer && s.south.connected && s.north.connected)
+      if (int rc = upload_multi_peer(c, s)) return rc;
   }
   return alloc_partials(c);
 }
@@ -2069,6 +2152,12 @@ int upload_multi_peer(const lbm_ctx *c, Slab &s) {
   h.push_rows = s.row0;
   h.row_lo0 = s.row0;      // bottom edge rows [row0, 2 row0) -> the south neighbour's top halo rows
   h.row_hi0 = s.rows;      // top edge rows [rows, rows + row0) -> the north neighbour's bottom halo rows
+  if (slab_twin5(c) && s.row0 > kDeepTwinDefault) {
+    // the five-step chunk pairs on slabs that store more halo rows than they exchange: the five rows next to the owned ones
+    h.push_rows = kDeepTwinDefault;
+    h.row_hi0 = s.row0 + s.rows - kDeepTwinDefault;
+    for (int b = 0; b < 2; b++) h.push[1][b] = s.north.cells[b] + (size_t)(s.row0 - kDeepTwinDefault) * s.row_stride;
+  }
   if (set_dev(s)) return LBM_ERR_HIP;
   if (!s.d_peer && dev_alloc(&s.d_peer, 1)) return LBM_ERR_HIP;
   HIP_TRY(hipMemcpy(s.d_peer, &h, sizeof h, hipMemcpyHostToDevice));
@@ -2234,6 +2323,10 @@ static int create_common(lbm_ctx **out, const lbm_params *params, const int32_t 
     // ... and slabs of 5M cells and more depth 8 again: d2q9_deep, up to eight steps per launch set
     if ((long)params->nx * rows_min >= kSlabDeepCells && rows_min >= 4 * kDeepSteps && params->nx % 4 == 0 && params->nx >= 256)
       c->halo_depth = kDeepSteps;
+    // ... and slabs between 540K and 3M cells depth 5: five-step chunk pairs in compact launch sets (kSlabTwinCells)
+    // (slabs in the LDS tiles' range keep their eight: the pairs use five of them)
+    else if (!small && rows_min >= 4 * kDeepTwinDefault && params->nx % 4 == 0 && params->nx >= 256)
+      c->halo_depth = kDeepTwinDefault;
     if (g_defaults.halo_depth > 0) c->halo_depth = g_defaults.halo_depth;
     if (rows_min < 2 * c->halo_depth) c->halo_depth = 2;
   }
@@ -2598,7 +2691,8 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
     return c->halo_mode ? rebuild_geometry(c) : LBM_OK;   // (whether launch sets are compact depends on it)
   }
   if (!strcmp(key, "fuse")) {
-    if (value < -1 || value > kDeepSteps || value == 5) return fail(LBM_ERR_ARG, "fuse must be -1 (auto), 0, 1 (or 2), 3, 4 or 6..8");
+    // (5: the five-step chunk pairs of row slabs with five halo rows in compact launch sets, slab_twin5; the four-step kernel elsewhere)
+    if (value < -1 || value > kDeepSteps) return fail(LBM_ERR_ARG, "fuse must be -1 (auto), 0, 1 (or 2), 3 .. 8");
     c->fuse = (int)value;
     return c->halo_mode ? rebuild_geometry(c) : LBM_OK;
   }
@@ -2749,14 +2843,14 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
-  else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? (c->halo_mode ? (compact_sets(c) && c->slabs[0].f6_main.paired) : deep_twin_effective(c)) : fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
+  else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : slab_twin5(c) ? 1 : (fuse_level(c) >= kDeepMin ? (c->halo_mode ? (compact_sets(c) && c->slabs[0].f6_main.paired) : deep_twin_effective(c)) : fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);
   else if (!strcmp(key, "load_bufs")) *value = step3_load_bufs(c);
   else if (!strcmp(key, "launch_steps")) {
     // most timesteps one launch (launch set) of the context's main kernel advances
     const int ms = multistep_effective(c), lvl = fuse_level(c);
-    *value = ms > 0 ? ms : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, twin_cap(c)) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
+    *value = ms > 0 ? ms : slab_twin5(c) ? kDeepTwinDefault : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, twin_cap(c)) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
   }
-  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : (fuse_level(c) >= kDeepMin ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
+  else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : ((fuse_level(c) >= kDeepMin || slab_twin5(c)) ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;
   else if (!strcmp(key, "steady")) *value = c->steady != 0;
   else if (!strcmp(key, "balance")) {

@@ -319,7 +319,10 @@ def test_transport_self_ring(transport):
                                                                    # one round with a late pair / the tapered multi-round schedule
                                                                    (2, 8192, 1408, 23, 8, 0, 0), (3, 8192, 4200, 16, 8, 0, 2),
                                                                    # ... with a cavity's side walls: balanced wall strips + free sweeps on every rank
-                                                                   (2, 8192, 1408, 23, 8, 0, "walls"), (3, 8192, 2112, 16, 8, 0, "walls")])
+                                                                   (2, 8192, 1408, 23, 8, 0, "walls"), (3, 8192, 2112, 16, 8, 0, "walls"),
+                                                                   # slabs with five halo rows: d2q9_deep_twin<5, ..., PUSH>, edge chunk pairs (the shipped 1024x1024
+                                                                   # input over 2 and 4 ranks has these shapes)
+                                                                   (2, 1024, 1024, 23, 5, -1, 0), (4, 1024, 1024, 36, 5, -1, 0), (3, 2048, 1500, 16, 5, -1, 2)])
 def test_peer_transport_between_processes(world, nx, ny, nsteps, fuse, multistep, sync):
     """the peer transport across PROCESS boundaries: `world` processes share the one GPU, each owns a row slab, maps
     its neighbours' grids and flag words through HIP IPC, pushes its edge rows into them and waits on its own flags
@@ -429,19 +432,55 @@ def test_row_slabs_large_fused(lbm):
         assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
 
 
-def test_row_slabs_of_2m_cells_use_four_steps_and_halo_depth_4(lbm):
-    """8192x512 over 2 slabs: each slab holds 2M cells, so the library picks halo depth 4 and d2q9_step4 by itself"""
+@pytest.mark.parametrize("transport,fuse,launch_steps", [("peer", 5, 5), ("copy", 4, 4)])
+def test_row_slabs_of_2m_cells_carry_five_halo_rows(lbm, transport, fuse, launch_steps, halo_defaults):
+    """8192x512 over 2 slabs: each slab holds 2M cells, so the library picks halo depth 5 by itself — the five-step chunk pairs
+    in compact launch sets (peer stores), d2q9_step4 on two streams (copies)"""
+    halo_defaults(transport=transport)
     rng = np.random.default_rng(10)
     nx, ny, nsteps = 8192, 512, 14
     ob, cells0 = random_case(rng, nx, ny, blocked=0.02)
     p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
     one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
     with lbm.LBM(p, ob, devices=[0, 0]) as sim:
-        assert sim.get_option("fuse") == 4 and sim.get_option("multistep") == 0
+        assert sim.get_option("halo_depth") == 5 and sim.get_option("fuse") == fuse and sim.get_option("multistep") == 0
+        assert sim.get_option("launch_steps") == launch_steps
         sim.upload(cells0)
         sim.run(nsteps)
         many, av_many = sim.download()
     assert np.array_equal(one, many) and max_rel(av_many, av_one) < 2e-6
+
+
+@pytest.mark.parametrize("nslabs,nx,ny", [(1, 1024, 512), (2, 1024, 640), (4, 2048, 1024), (3, 1024, 2000), (2, 256, 2600), (8, 1024, 2560)])
+@pytest.mark.parametrize("nsteps,halo_sync,nt,paths", [(23, 0, -1, -1), (16, 2, -1, -1), (11, 0, 1, -1), (7, 0, -1, 0), (1, 0, -1, -1)])
+def test_row_slabs_five_step_chunk_pairs(lbm, nslabs, nx, ny, nsteps, halo_sync, nt, paths, halo_defaults):
+    """row slabs of 300K to 3M cells (what the shipped 1024x1024 input gives 2 GPUs): five halo rows exchanged (of five stored above
+    540K cells per slab, of the eight the LDS tiles' range stores below), compact launch sets
+    of d2q9_deep_twin<5, ..., PUSH> — the five rows at either end of a slab are a chunk pair of their own (2 + 3 rows), every edge
+    wave pushes its rows into the ring neighbour, the interior is one round of chunk pairs; launch sets of 5 + 5 + 5 + 4 + 4
+    (per-depth kernel and the any-depth one), 4 x 4, 4 + 4 + 3, 4 + 3 and a single step; one slab as its own neighbour, uneven
+    splits (667 / 666 rows), a narrow grid (3 strips), 8 slabs; wait kernel and in-kernel wait; bit-identical to single steps"""
+    if nslabs == 1:
+        halo_defaults(force_halo=1)
+    rng = np.random.default_rng(500 + nslabs)
+    ob, cells0 = random_case(rng, nx, ny, blocked=0.03)
+    ob[0, :] = 0
+    ob[-1, :] = 0  # open top/bottom: the y wrap-around between the last and the first slab carries flow
+    ob[ny // 3: ny // 3 + 40, :] = 0  # a band without blocked cells: both collision paths
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob, devices=[0] * nslabs) as sim:
+        sim.set_option("halo_sync", halo_sync)
+        sim.set_option("nt_stores", nt)
+        sim.set_option("obst_paths", paths)
+        assert sim.get_option("halo_depth") == (5 if nx * (ny // nslabs) > 540 * 1024 else 8)
+        assert sim.get_option("fuse") == 5 and sim.get_option("multistep") == 0
+        assert sim.get_option("compact") == 1 and sim.get_option("pair") == 1 and sim.get_option("launch_steps") == 5
+        sim.upload(cells0)
+        sim.run(nsteps)
+        many, av_many = sim.download()
+    assert np.array_equal(one, many)
+    assert max_rel(av_many, av_one) < 2e-6
 
 
 def test_row_slabs_split_runs_and_shipped_geometry(lbm, oracle_f32_omp):
