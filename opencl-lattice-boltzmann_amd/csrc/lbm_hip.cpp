@@ -241,6 +241,12 @@ struct Slab {
   uint32_t *halo_flags = nullptr;
   PeerLink south, north;
   lbm::HaloPeer *d_peer = nullptr;   // device copy of what the fused push / wait of d2q9_multi needs (filled when the ring is connected)
+  // staged launch sets (RCCL transport + the deep window kernel, staged_sets): the edge units of the ONE launch store their rows a second
+  // time into these two blocks of halo-depth rows (write-through, as into a peer's halo rows) and the last edge wave raises halo_flags[4]
+  // and [5]; the edge stream waits on those words and sends from the blocks
+  float *stage[2] = {nullptr, nullptr};
+  lbm::HaloPeer *d_stage_peer = nullptr;
+  int can_wait_value = 0;            // hipDeviceAttributeCanUseStreamWaitValue
   double *av_tmp = nullptr;   // all-reduce target of the velocity record (rank mode), allocated on first use
   // output-stage scratch
   float *fin_partials = nullptr;
@@ -475,7 +481,20 @@ int multistep_effective(const lbm_ctx *c) {
 // tiles / edge chunks, which store the halo rows into the ring neighbours themselves and raise their flag words — instead
 // of edge launch + push kernel on an edge stream beside the interior launch.  For the LDS-tile kernel and for the
 // three- / four-step kernels in their default form (LDS windows, one row-set of loads in flight, plain loads).
+// Staged launch sets: the compact launch form under the RCCL transport, for slabs that run the deep window kernel.  ONE launch per
+// set on the main stream — edge units first, chunk pairs, balanced: the kernel and schedule of the peer transport — whose edge units
+// push their rows into a local staging block instead of a neighbour; the edge stream waits for the flag word the last edge wave raises
+// (hipStreamWaitValue32), sends the blocks and receives into the halo rows while the interior is still running, and the next launch waits
+// for that exchange's event.  Two-stream sets (edge launch + interior launch of the lone kernel) ran the 8192x1024 slab at 335 GLUPS per
+// rank against 404 over peer stores; option "compact" 0 brings them back.
+bool staged_sets(const lbm_ctx *c) {
+  if (!c->halo_mode || c->transport_eff != TRANSPORT_RCCL || c->compact == 0 || c->slabs.empty()) return false;
+  for (const Slab &s : c->slabs)
+    if (!s.can_wait_value) return false;
+  return multistep_effective(c) == 0 && fuse_level(c) >= kDeepMin;
+}
 bool compact_sets(const lbm_ctx *c) {
+  if (staged_sets(c)) return true;
   if (!compact_transport(c)) return false;
   if (slab_twin5(c)) return true;    // d2q9_deep_twin<5, .., PUSH>
   if (multistep_effective(c) > 0) return true;
@@ -777,16 +796,19 @@ int deep_geometry(const lbm_ctx *c, Slab &s) {
     // (two-stream launch sets — RCCL, copies — keep the lone kernel: an interior launch of pairs next to the edge launch and the
     // exchange kernel was measured at 200 against 292 GLUPS on the 8192x1024 ring of one: the 40-KB pair workgroups crowd them out)
     if (c->pair != 0 && c->edge_aware != 0 && compact_sets(c)) {
+      // (staged launch sets: NO late pair — the slots the edge workgroups free are where the exchange kernel of the edge stream runs,
+      // on CUs whose other wave slots hold interior waves at 244 registers each)
+      const bool late = !staged_sets(c);
       const int n_pairs = (slots - edge_work) / (2 * vs);
-      const int Rp = n_pairs > 0 ? div_up(rows + 2 * delay, 2 * n_pairs + 2) : 0;
-      const int rp_late = Rp - delay;
+      const int Rp = n_pairs > 0 ? (late ? div_up(rows + 2 * delay, 2 * n_pairs + 2) : div_up(rows, 2 * n_pairs)) : 0;
+      const int rp_late = late ? Rp - delay : 4;
       if (n_pairs >= 1 && Rp <= c6one && rp_late >= 4) {
         std::vector<int> starts;
         int y = i0, left = rows;
-        const int nch = 2 * n_pairs + 2;
+        const int nch = late ? 2 * n_pairs + 2 : 2 * n_pairs;
         for (int k = 0; k < nch; k++) {
           const int remaining_full = std::max(0, 2 * n_pairs - k);
-          int sz = k < 2 * n_pairs ? div_up(std::max(0, left - 2 * rp_late), std::max(1, remaining_full)) : std::min(rp_late, left);
+          int sz = k < 2 * n_pairs ? div_up(std::max(0, left - (late ? 2 * rp_late : 0)), std::max(1, remaining_full)) : std::min(rp_late, left);
           if (k == nch - 1) sz = left;
           sz = std::max(0, std::min(sz, left));
           starts.push_back(y);
@@ -1373,9 +1395,9 @@ int wait_halos(lbm_ctx *c, Slab &s, hipStream_t st, uint32_t seq) {
 
 // Slab mode: move the `halo_depth` bottom and top owned rows of grid `buf` into the ring neighbours' halo
 // rows of their grid `buf`.  Each group of rows is one contiguous block of halo_depth*row_stride floats.
-int exchange_halos(lbm_ctx *c, int buf, int evq, bool on_main = false) {
+int exchange_halos(lbm_ctx *c, int buf, int evq, bool on_main = false, bool staged = false) {
   const int P = c->nslabs_global;
-  const bool stale = stale_exchange_now(c);
+  const bool stale = !staged && stale_exchange_now(c);  // (a staged set has asked the hook before its launch)
   if (c->transport_eff == TRANSPORT_PEER) {
     const uint32_t seq = c->halo_seq + 1;
     for (Slab &s : c->slabs) {
@@ -1411,8 +1433,8 @@ int exchange_halos(lbm_ctx *c, int buf, int evq, bool on_main = false) {
       b.count = (size_t)s.row0 * s.row_stride;
       b.north = (s.index + 1) % P;
       b.south = (s.index + P - 1) % P;
-      b.send_north = g + (size_t)s.rows * s.row_stride;
-      b.send_south = g + (size_t)s.row0 * s.row_stride;
+      b.send_north = staged ? s.stage[1] : g + (size_t)s.rows * s.row_stride;   // (staged sets: the blocks the edge units have filled)
+      b.send_south = staged ? s.stage[0] : g + (size_t)s.row0 * s.row_stride;
       b.recv_south = g;
       b.recv_north = g + (size_t)(s.row0 + s.rows) * s.row_stride;
       b.comm = s.comm;
@@ -1473,6 +1495,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
   }
   // compact launch sets (small slabs, peer transport): everything on the main stream
   const bool compact = compact_sets(c);
+  const bool staged = staged_sets(c);  // (a compact form: the pushes go to local staging blocks, the exchange is RCCL's on the edge stream)
   if (multi) {
     // halos of the initial state ("launch set -1", event parity 1)
     for (Slab &s : c->slabs) {
@@ -1482,11 +1505,16 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[1], 0));
     }
     if (int rc = exchange_halos(c, c->cur, 1, compact)) return rc;
+    if (staged)  // the first launch is ordered behind this exchange as every later one behind its predecessor's
+      for (Slab &s : c->slabs) {
+        if (set_dev(s)) return LBM_ERR_HIP;
+        HIP_TRY(hipEventRecord(s.ev_edgek[1], s.s_edge));
+      }
   }
   if (timed)
     for (Slab &s : c->slabs) {
       if (set_dev(s)) return LBM_ERR_HIP;
-      if (multi && !compact) {
+      if (multi && (!compact || staged)) {
         // start the clock on the main stream once the initial halos have landed
         HIP_TRY(hipEventRecord(s.ev_aux, s.s_edge));
         HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_aux, 0));
@@ -1640,7 +1668,10 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       }
       if (compact && kind == KIND_DEEP) {
         // ---- compact launch set of d2q9_deep: as for the three- / four-step kernels below
-        if (c->halo_sync != 2)
+        // (staged: behind the previous set's exchange on the edge stream — its received rows are this launch's halo rows, its
+        // sent blocks the ones this launch's edge units overwrite)
+        if (staged) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));
+        else if (c->halo_sync != 2)
           if (int rc = wait_halos(c, s, s.s_main, c->halo_seq)) return rc;
         Step2Args a = base_args2(c, s, src, !last, s.f6_main);
         a.edge_chunk_start = s.f6_edge.chunk_start;
@@ -1648,8 +1679,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         a.edge_units = s.f6_edge.units;
         a.edge_skip = s.f6_edge.skip;
         a.edge_partial_off = s.f6_main.units;
-        a.peer = s.d_peer;
-        if (c->halo_sync == 2) {
+        a.peer = staged ? s.d_stage_peer : s.d_peer;
+        if (c->halo_sync == 2 && !staged) {
           a.peer_mode |= 2;
           a.wait_seq = c->halo_seq;
         }
@@ -1661,7 +1692,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
         if (int rc = mark(s, 3, s.s_main)) return rc;
         launch_deep_compact(c, s, a, slot1, adv, s.s_main);
         HIP_TRY(hipGetLastError());
-        if (stale_set)
+        if (stale_set && !staged)
           if (int rc = publish_flags_only(c, s, c->halo_seq + 1, s.s_main)) return rc;
         if (int rc = mark(s, 4, s.s_main)) return rc;
         continue;
@@ -1708,6 +1739,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       // pushes of the latest exchange, announced in this slab's flag words) and interior (event)
       if (c->transport_eff == TRANSPORT_PEER)
         if (int rc = wait_halos(c, s, s_edge, c->halo_seq)) return rc;
+      if (staged) HIP_TRY(hipStreamWaitEvent(s.s_main, s.ev_edgek[qp], 0));  // (the previous set's exchange ran on the edge stream)
       if (!compact) {
         HIP_TRY(hipStreamWaitEvent(s.s_edge, s.ev_main[qp], 0));
         // interior launch: needs the previous set's edge rows
@@ -1810,7 +1842,26 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (int rc = mark(s, 1, s_edge)) return rc;
       if (int rc = mark(s, 4, s.s_main)) return rc;
     }
-    if (compact_set) {
+    if (compact_set && staged) {
+      // the exchange of a staged set: the edge stream waits for the words the set's last edge wave raises, then RCCL sends the
+      // staging blocks and receives into the halo rows of the grid the set has written — beside the set's interior units
+      if (!last) {
+        c->halo_seq++;
+        if (!stale_set) {  // (test hook: no push, no exchange — the next set reads what its halo rows held before)
+          for (Slab &s : c->slabs) {
+            if (set_dev(s)) return LBM_ERR_HIP;
+            HIP_TRY(hipStreamWaitValue32(s.s_edge, s.halo_flags + 4, c->halo_seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            HIP_TRY(hipStreamWaitValue32(s.s_edge, s.halo_flags + 5, c->halo_seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+          }
+          if (int rc = exchange_halos(c, src ^ 1, q, false, true)) return rc;
+        }
+        for (Slab &s : c->slabs) {
+          if (set_dev(s)) return LBM_ERR_HIP;
+          HIP_TRY(hipEventRecord(s.ev_edgek[q], s.s_edge));
+        }
+      }
+      if (int rc = mark(c->slabs[0], 2, c->slabs[0].s_edge)) return rc;
+    } else if (compact_set) {
       if (!last) c->halo_seq++;     // the edge units of this set's launches have pushed exchange number halo_seq
     } else if (multi) {
       if (!last)
@@ -1914,6 +1965,11 @@ void free_slab(Slab &s) {
     if (l->flags) hipIpcCloseMemHandle(l->flags);
   }
   if (s.halo_flags) hipFree(s.halo_flags);
+  for (int k = 0; k < 2; k++)
+    if (s.stage[k]) hipFree(s.stage[k]);
+  if (s.d_stage_peer) hipFree(s.d_stage_peer);
+  s.stage[0] = s.stage[1] = nullptr;
+  s.d_stage_peer = nullptr;
   if (s.d_peer) hipFree(s.d_peer);
   if (s.av_tmp) hipFree(s.av_tmp);
   if (s.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(s.comm);
@@ -1996,6 +2052,7 @@ int build_slab(lbm_ctx *c, Slab &s, const int32_t *obstacles) {
   if (multi) {
     if (dev_alloc(&s.halo_flags, 64)) return LBM_ERR_HIP;
     HIP_TRY(hipMemset(s.halo_flags, 0, 64 * sizeof(uint32_t)));
+    HIP_TRY(hipDeviceGetAttribute(&s.can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, s.dev));
   }
   s.fin_blocks = std::max(1, std::min(div_up((long)nx * s.rows, kBlock), 2048));
   if (dev_alloc(&s.fin_partials, (size_t)s.fin_blocks)) return LBM_ERR_HIP;
@@ -2018,6 +2075,35 @@ int alloc_partials(lbm_ctx *c) {
 }
 
 int upload_multi_peer(const lbm_ctx *c, Slab &s);
+// staged launch sets: the slab's staging blocks (allocated on first use) and the device-side description that makes the edge units of
+// a PUSH kernel store into them and raise halo_flags[4], [5]
+int upload_stage_peer(const lbm_ctx *c, Slab &s) {
+  if (set_dev(s)) return LBM_ERR_HIP;
+  const size_t count = (size_t)s.row0 * s.row_stride;
+  for (int k = 0; k < 2; k++)
+    if (!s.stage[k]) {
+      if (dev_alloc(&s.stage[k], count)) return LBM_ERR_HIP;
+      HIP_TRY(hipMemset(s.stage[k], 0, count * sizeof(float)));  // (the padding behind nx is never written: sent as zeros)
+    }
+  HaloPeer h{};
+  for (int b = 0; b < 2; b++) {
+    h.push[0][b] = s.stage[0];
+    h.push[1][b] = s.stage[1];
+  }
+  h.flag_lo = s.halo_flags + 4;
+  h.flag_hi = s.halo_flags + 5;
+  h.ticket = s.halo_flags + 3;
+  h.wait_flags = s.halo_flags;
+  h.wait_err = s.halo_flags + 2;
+  h.wait_ticks = c->halo_timeout_ms * kTicksPerMs;
+  h.push_rows = s.row0;
+  h.row_lo0 = s.row0;
+  h.row_hi0 = s.rows;
+  h.release = 0;  // write-through stores into this device's own memory, drained before the ticket; the exchange kernel starts behind the flag
+  if (!s.d_stage_peer && dev_alloc(&s.d_stage_peer, 1)) return LBM_ERR_HIP;
+  HIP_TRY(hipMemcpy(s.d_stage_peer, &h, sizeof h, hipMemcpyHostToDevice));
+  return LBM_OK;
+}
 int rebuild_geometry(lbm_ctx *c) {
   // grid_blocks / chunk changes alter the number of partial sums per step
   for (Slab &s : c->slabs) {
@@ -2028,6 +2114,9 @@ int rebuild_geometry(lbm_ctx *c) {
     if (s.d_peer && s.south.connected && s.north.connected)
       if (int rc = upload_multi_peer(c, s)) return rc;
   }
+  if (staged_sets(c))
+    for (Slab &s : c->slabs)
+      if (int rc = upload_stage_peer(c, s)) return rc;
   return alloc_partials(c);
 }
 

@@ -13,8 +13,55 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lbm_amd
 
-transport = sys.argv[1]  # "rccl", "copy" or "peer"
+transport = sys.argv[1]  # "rccl", "copy" or "peer"; "rccl_deep": the staged launch sets of a slab big enough for the deep window kernel
 rng = np.random.default_rng(21)
+if transport == "rccl_deep":
+    # RCCL + d2q9_deep: ONE launch per launch set (edge units first, interior chunk pairs, side walls balanced, free sweeps) whose edge
+    # units store their rows into the slab's staging blocks; the edge stream waits on the flag word (hipStreamWaitValue32), sends the
+    # blocks to itself and receives into the halo rows beside the running interior.  23 steps = 8 + 8 + 7; the two-stream form
+    # ("compact" 0); split runs; and the test hook: an exchange that delivers nothing must change the result
+    nx, ny, nsteps = 8192, 416, 23
+    ob = (rng.random((ny, nx)) < 0.0002).astype(np.int32)
+    ob[0, :] = ob[-1, :] = 0
+    ob[:, 0] = ob[:, -1] = 1
+    ob[100:300, 64:-64] = 0
+    w = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4, dtype=np.float64).reshape(9, 1, 1) * 0.1
+    cells0 = (w * (1.0 + 0.2 * (rng.random((9, ny, nx)) - 0.5))).astype(np.float32)
+    p = lbm_amd.make_params(nx, ny, nsteps, obstacles=ob)
+    with lbm_amd.LBM(p, ob) as sim:
+        sim.set_option("fuse", 0)
+        sim.set_option("multistep", 0)
+        sim.upload(cells0)
+        sim.run(nsteps)
+        ref, av_ref = sim.download()
+    lbm_amd.set_default("force_halo", 1)
+    lbm_amd.set_default("transport", "rccl")
+    for (compact, pair, split, stale) in ((-1, -1, 0, 0), (-1, 0, 0, 0), (0, -1, 0, 0), (-1, -1, 9, 0), (-1, -1, 0, 2)):
+        with lbm_amd.LBM(p, ob, rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) as sim:
+            sim.set_option("compact", compact)
+            sim.set_option("pair", pair)
+            assert sim.get_option("transport") == 1 and sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8
+            assert sim.get_option("compact") == (1 if compact else 0) and sim.get_option("pair") == (1 if compact and pair else 0)
+            if stale:
+                sim.set_option("debug_stale_exchange", stale)
+            sim.upload(cells0)
+            if split:
+                sim.run(split)
+                sim.sync()
+            sim.run(nsteps - split)
+            got, av = sim.download()
+        tag = "rccl staged sets: compact %d pair %d split %d stale %d" % (compact, pair, split, stale)
+        same = np.array_equal(got, ref)
+        if stale:
+            assert not same, tag + ": a lost exchange went unnoticed"
+        else:
+            if not same:
+                bad = np.argwhere(np.any(got != ref, axis=(0, 2))).ravel()
+                raise AssertionError("state differs (%s): %d rows, first %s, last %s" % (tag, bad.size, bad[:6], bad[-6:]))
+            assert np.max(np.abs(av - av_ref) / av_ref) < 2e-6, tag
+        print("ok:", tag, flush=True)
+    print("self-ring ok:", transport)
+    sys.exit(0)
 nx, ny, nsteps = 512, 96, 23
 ob = (rng.random((ny, nx)) < 0.05).astype(np.int32)
 ob[0, :] = ob[-1, :] = 0

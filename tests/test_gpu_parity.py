@@ -298,12 +298,13 @@ def test_row_slabs_equal_single_slab(lbm, nslabs, ny, mode):
     assert max_rel(av_many, av_one) < 2e-6           # only the summation order of av_vels differs
 
 
-@pytest.mark.parametrize("transport", ["copy", "rccl", "peer"])
+@pytest.mark.parametrize("transport", ["copy", "rccl", "peer", "rccl_deep"])
 def test_transport_self_ring(transport):
     """the halo-exchange machinery with ONE slab that is its own ring neighbour, once per transport: rccl = every
     exchange is ncclSend/ncclRecv (to self) on a communicator made by ncclCommInitRank and av_vels go through
     ncclAllReduce — the code path of the one-process-per-GPU launch; peer = halo_push kernel + flag words with both
-    consumer-side waits, and a context that switches between RCCL and peer stores mid-run"""
+    consumer-side waits, and a context that switches between RCCL and peer stores mid-run; rccl_deep = the staged launch sets of
+    the deep window kernel under RCCL (one launch per set, pushes into local staging blocks, exchange behind a stream wait-value)"""
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_self_ring.py"), transport],
                        capture_output=True, text=True, timeout=300)
