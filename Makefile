@@ -64,7 +64,7 @@ oracle-asan:
 
 # stand-alone measurement programs (not part of the product): tools/barrier_probe (grid barriers against launch boundaries,
 # profiles/r03_persistent_kernel_negative.txt), tools/deep_probe (the harness the deep window kernel was built in)
-probes: tools/barrier_probe tools/deep_probe
+probes: tools/barrier_probe tools/deep_probe tools/resident_probe
 tools/%: tools/%.cpp
 	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -I/opt/rocm/include $< -o $@
 

@@ -2246,6 +2246,194 @@ __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, floa
   }
 }
 
+// ---- all timesteps of a run in ONE launch, the grid resident in registers ("resident" kernel) ------------------
+// The latency-bound sizes (512x512 ... 1024x1024: the sizes the reference publishes) pay, in every kernel above, a pass
+// through memory per launch and a launch per <= 8 steps: d2q9_deep_twin<5> runs 1024x1024 at 5.8 us/step, of which ~2.4 us is
+// arithmetic.  Here the grid never leaves the chip between the steps of an lbm_run: 1024x1024 cells x 36 B = 37.7 MB against
+// 128 MB of vector registers.  A WORKGROUP of W waves owns a band of BH full-width rows (W = nx / 128: a wave holds 64 lanes of
+// two cells x BH rows x 9 planes = 18 BH registers), one workgroup per CU at W = 8, all of them co-resident; per timestep
+//   - the waves of a band trade their edge cells (x neighbours, periodic wrap included) through LDS: one barrier;
+//   - a wave stores the three planes of its top row that move up and of its bottom row that move down into the band's
+//     exchange rows in memory (double-buffered by step parity; 8-byte agent-scope write-through stores, drained), then
+//     raises its step word; the rows between (BH - 2 of them) need nothing from outside and are collided while the words
+//     travel; then the wave polls the step words of the three waves above and the three below it (bounded spin, one timeout
+//     per run), loads their rows and collides its bottom and top row.
+// No launch boundary, no start-up rows, no halo lanes, no redundant cell: 2 cells x 88 packed instructions per lane, row and
+// step — and one neighbour hand-shake per step on the critical path (tools/resident_probe.cpp: 2.2 us, 2.85 us per step with the
+// arithmetic of four rows; two steps per hand-shake on two-row halos come out the same).  In-place update: the rows are
+// collided in the order 1 .. BH-2, 0, BH-1 and the few planes a later row still needs of an overwritten one are kept aside.
+// Same collide2 as d2q9_deep on the same pairs of cells: bit-identical to single steps.
+struct ResidentArgs {
+  const float *src;          // the grid at the first step (row-interleaved planes, as everywhere)
+  float *dst;                // ... after the last
+  const uint8_t *mask;
+  float *partials;           // [nsteps][pstride]: slot band * W + wave = that wave's sum of |j|/rho per step
+  unsigned long long plane_stride, row_stride, pstride;
+  int nx, ny, nsteps;
+  int accel_row;             // global row ny-2 (-1: none)
+  int accel_next;            // apply the following step's accelerate_flow after the LAST step too
+  float omega, aw1, aw2;
+  unsigned *words;           // [bands][32]: a band's W step words in one 128-byte line
+  float *xrows;              // [2 parity][bands][2 dir][3 planes][nx]: dir 0 = a band's top row (planes 2,5,6), dir 1 = its bottom row (4,7,8)
+  unsigned seq_base;         // the words reach seq_base + 1 + (steps done in this launch)
+  unsigned *err;
+  unsigned long long wait_ticks;
+};
+
+__device__ __forceinline__ void resident_store(float *p, v2f v) {
+  global_u64 *q = (global_u64 *)(unsigned long long)p;
+  const unsigned long long bits = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+  __hip_atomic_store(q, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ v2f resident_load(const float *p) {
+  const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v2f v = {__uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32))};
+  return v;
+}
+__device__ __forceinline__ float resident_load1(const float *p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int BH, int W>
+__global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
+  static_assert(BH >= 2 && BH <= 4 && W >= 1 && W <= 8, "band shape");
+  // x exchange inside the band: [parity][wave][row][3]: east[.] = planes 1,5,8 of the wave's last cell, west[.] = 3,6,7 of its first
+  __shared__ float xe[2][W][BH][4], xw[2][W][BH][4];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int band = blockIdx.x, nbands = gridDim.x;
+  const int x0 = w * 128, xcol = x0 + 2 * lane;
+  const size_t ps = a.plane_stride, rs = a.row_stride;
+  const int wl = (w + W - 1) % W, wr = (w + 1) % W;
+  const int bdn = (band + nbands - 1) % nbands, bup = (band + 1) % nbands;
+  v2f f[BH][9];
+  uint32_t m[BH];
+  bool blocked[BH];  // wave-uniform: a blocked cell in this wave's part of the row
+#pragma unroll
+  for (int r = 0; r < BH; r++) {
+    const size_t row = (size_t)(band * BH + r);
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[r][k] = *reinterpret_cast<const v2f *>(a.src + row * rs + k * ps + xcol);
+    m[r] = (*reinterpret_cast<const uint32_t *>(a.mask + row * a.nx + (xcol & ~3)) >> ((xcol & 2) * 8)) & 0xffffu;
+    blocked[r] = __builtin_amdgcn_ballot_w64(m[r] != 0u) != 0ull;
+  }
+  const size_t xr_dir = (size_t)3 * a.nx, xr_band = 2 * xr_dir, xr_par = (size_t)nbands * xr_band;
+  // (a band's W step words share one 128-byte line: the three words a wave polls per side are one memory transaction)
+  unsigned *const my_word = a.words + (size_t)band * 32 + w;
+  // the step words this wave waits for: lanes 0..2 the band below (waves wl, w, wr), lanes 3..5 the band above
+  const unsigned *poll = a.words + (size_t)(lane < 3 ? bdn : bup) * 32 + (lane % 3 == 0 ? wl : (lane % 3 == 1 ? w : wr));
+  auto publish = [&](unsigned seq) __attribute__((always_inline)) {
+    float *base = a.xrows + (size_t)(seq & 1u) * xr_par + (size_t)band * xr_band + xcol;
+    resident_store(base + 0 * a.nx, f[BH - 1][2]);
+    resident_store(base + 1 * a.nx, f[BH - 1][5]);
+    resident_store(base + 2 * a.nx, f[BH - 1][6]);
+    resident_store(base + xr_dir + 0 * a.nx, f[0][4]);
+    resident_store(base + xr_dir + 1 * a.nx, f[0][7]);
+    resident_store(base + xr_dir + 2 * a.nx, f[0][8]);
+    drain_stores();  // write-through stores: acknowledged = they have left this XCD
+    if (lane == 0) __hip_atomic_store(my_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  publish(a.seq_base + 1u);
+  for (int s = 0; s < a.nsteps; s++) {
+    const unsigned seq = a.seq_base + 1u + (unsigned)s;   // the neighbours' rows of the state this step starts from
+    const int par = s & 1;
+    const bool accel_ok = (s + 1 < a.nsteps) || a.accel_next;
+    // ---- x neighbours through LDS
+    if (lane == 63) {
+#pragma unroll
+      for (int r = 0; r < BH; r++) { xe[par][w][r][0] = f[r][1].y; xe[par][w][r][1] = f[r][5].y; xe[par][w][r][2] = f[r][8].y; }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < BH; r++) { xw[par][w][r][0] = f[r][3].x; xw[par][w][r][1] = f[r][6].x; xw[par][w][r][2] = f[r][7].x; }
+    }
+    __syncthreads();
+    float hw[BH][3], he[BH][3];  // west halos of planes 1,5,8 / east halos of planes 3,6,7, by the row they are stored in
+#pragma unroll
+    for (int r = 0; r < BH; r++) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { hw[r][k] = xe[par][wl][r][k]; he[r][k] = xw[par][wr][r][k]; }
+    }
+    float sum = 0.f;
+    // one row: south = planes 2,5,6 of the row below (+ their x halos: west of 5, east of 6), north = planes 4,7,8 of the row above
+    // (west of 8, east of 7)
+    auto collide_row = [&](int r, const v2f (&south)[3], float s5w, float s6e, const v2f (&north)[3], float n8w, float n7e) __attribute__((always_inline)) {
+      v2f g[9], o[9];
+      g[0] = f[r][0];
+      g[1] = pair_from_west(f[r][1], hw[r][0]);
+      g[3] = pair_from_east(f[r][3], he[r][0]);
+      g[2] = south[0];
+      g[5] = pair_from_west(south[1], s5w);
+      g[6] = pair_from_east(south[2], s6e);
+      g[4] = north[0];
+      g[7] = pair_from_east(north[1], n7e);
+      g[8] = pair_from_west(north[2], n8w);
+      const bool acc = accel_ok && (band * BH + r == a.accel_row);
+      v2f t;
+      if (!blocked[r]) t = collide2<false>(g, 0u, a.omega, acc, a.aw1, a.aw2, o);
+      else t = collide2<true>(g, m[r], a.omega, acc, a.aw1, a.aw2, o);
+      sum += t.x + t.y;
+#pragma unroll
+      for (int k = 0; k < 9; k++) f[r][k] = o[k];
+    };
+    // the planes later rows still need of rows that get overwritten first
+    v2f prev256[3] = {f[0][2], f[0][5], f[0][6]};      // old row r-1, for row r
+    float prev5w = hw[0][1], prev6e = he[0][1];
+    v2f one478[3] = {f[BH > 2 ? 1 : 0][4], f[BH > 2 ? 1 : 0][7], f[BH > 2 ? 1 : 0][8]};  // old row 1, for row 0 (BH = 2: unused)
+#pragma unroll
+    for (int r = 1; r <= BH - 2; r++) {
+      const v2f keep[3] = {f[r][2], f[r][5], f[r][6]};
+      const v2f north[3] = {f[r + 1][4], f[r + 1][7], f[r + 1][8]};
+      collide_row(r, prev256, prev5w, prev6e, north, hw[r + 1][2], he[r + 1][2]);
+#pragma unroll
+      for (int k = 0; k < 3; k++) prev256[k] = keep[k];
+      prev5w = hw[r][1];
+      prev6e = he[r][1];
+    }
+    // (prev256 now holds the old row BH-2 — for BH = 2 the old row 0 — which row BH-1 reads)
+    // ---- y neighbours: wait for the step words, load the rows
+    if (lane < 6) {
+      // bounded spin; ONE timeout per run (a wait that has lasted 100 us looks at the error word other waits may have raised — not
+      // before: six lanes of 2048 waves reading one word on every step would make that word's memory channel the hand-shake)
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while ((int32_t)(__hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+        if (dt > a.wait_ticks) { atomicOr(a.err, 1u); break; }
+        if (dt > 10000ull && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const float *below = a.xrows + (size_t)(seq & 1u) * xr_par + (size_t)bdn * xr_band;           // its top row: planes 2,5,6
+    const float *above = a.xrows + (size_t)(seq & 1u) * xr_par + (size_t)bup * xr_band + xr_dir;  // its bottom row: planes 4,7,8
+    v2f hb[3], ha[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { hb[k] = resident_load(below + k * a.nx + xcol); ha[k] = resident_load(above + k * a.nx + xcol); }
+    // the corner elements: one cell beyond the wave's 128 (only lanes 0 and 63 use them)
+    const int xwest = (x0 + a.nx - 1) % a.nx, xeast = (x0 + 128) % a.nx;
+    float b5w = 0.f, b6e = 0.f, a8w = 0.f, a7e = 0.f;
+    if (lane == 0) { b5w = resident_load1(below + 1 * a.nx + xwest); a8w = resident_load1(above + 2 * a.nx + xwest); }
+    if (lane == 63) { b6e = resident_load1(below + 2 * a.nx + xeast); a7e = resident_load1(above + 1 * a.nx + xeast); }
+    if constexpr (BH > 2) {
+      collide_row(0, hb, b5w, b6e, one478, hw[1][2], he[1][2]);
+    } else {
+      const v2f north[3] = {f[1][4], f[1][7], f[1][8]};
+      collide_row(0, hb, b5w, b6e, north, hw[1][2], he[1][2]);
+    }
+    collide_row(BH - 1, prev256, prev5w, prev6e, ha, a8w, a7e);
+    if (s + 1 < a.nsteps) publish(seq + 1u);
+    const float tot = wave_sum(sum);
+    if (lane == 0) a.partials[(size_t)s * a.pstride + band * W + w] = tot;
+  }
+#pragma unroll
+  for (int r = 0; r < BH; r++) {
+    const size_t row = (size_t)(band * BH + r);
+#pragma unroll
+    for (int k = 0; k < 9; k++) *reinterpret_cast<v2f *>(a.dst + row * rs + k * ps + xcol) = f[r][k];
+  }
+}
+
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------
 // Grids of a few hundred cells a side are bound by launch latency, not bandwidth (one step of 128x128 is
 // ~2 us of work behind ~3.4 us of launch cost).  This kernel advances T <= kMultiMaxT steps per launch: a

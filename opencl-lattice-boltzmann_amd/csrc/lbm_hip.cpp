@@ -247,6 +247,12 @@ struct Slab {
   float *stage[2] = {nullptr, nullptr};
   lbm::HaloPeer *d_stage_peer = nullptr;
   int can_wait_value = 0;            // hipDeviceAttributeCanUseStreamWaitValue
+  // d2q9_resident (one slab, the grid resident in registers over all steps of a launch): bands of res_bh rows x res_w waves
+  int res_bh = 0, res_w = 0, res_bands = 0;   // 0 = the grid has no such decomposition
+  unsigned *res_words = nullptr;              // [bands][32]: a band's step words, one 128-byte line
+  float *res_xrows = nullptr;                 // [2][bands][2][3][nx] exchange rows
+  unsigned *res_err = nullptr;
+  unsigned res_seq = 0;                       // what the step words have reached
   double *av_tmp = nullptr;   // all-reduce target of the velocity record (rank mode), allocated on first use
   // output-stage scratch
   float *fin_partials = nullptr;
@@ -308,6 +314,7 @@ struct lbm_ctx {
   int free_sweeps = -1;     // d2q9_deep at the depths with a kernel of their own: 1 (and -1, auto) = a wave whose rows hold no blocked cell in its
                             // strip runs the sweep without obstacle handling (the map of Slab::clean_bits), 0 = every wave looks level by level
   int multistep = -1;       // T timesteps per launch on LDS tiles (d2q9_multi, small grids): -1 auto, 0 off, 1..8 = T
+  int resident = -1;        // d2q9_resident (all steps of a launch with the grid in registers): -1 auto, 0 off, 1 on where the grid allows
   int chunk_rows = 0;       // longest chunk (rows per work unit) of d2q9_step2 (0 = auto)
   int chunk_min = 0;        // shortest chunk at the tapered end of a band (0 = auto)
   bool vec4 = true;
@@ -459,6 +466,43 @@ int fuse_level(const lbm_ctx *c) {
   return lvl;
 }
 bool fuse_effective(const lbm_ctx *c) { return fuse_level(c) != 0; }
+
+// d2q9_resident: one slab without halo rows whose grid decomposes into bands of BH full-width rows x W = nx/128 waves that are
+// all resident at once (two waves per SIMD: 8 / W workgroups per CU); res_* are set by resident_geometry.
+bool resident_effective(const lbm_ctx *c) {
+  if (c->halo_mode || c->slabs.size() != 1 || c->slabs[0].res_bands <= 0) return false;
+  return c->resident > 0;
+}
+int resident_geometry(const lbm_ctx *c, Slab &s) {
+  s.res_bh = s.res_w = s.res_bands = 0;
+  if (c->halo_mode || c->resident == 0 || c->p.nx % 128 != 0 || c->p.nx / 128 > 8) return LBM_OK;
+  const int W = c->p.nx / 128;
+  if (W != 1 && W != 2 && W != 4 && W != 8) return LBM_OK;
+  const int capacity = s.cus * (8 / W);
+  int bh = 0;
+  for (int cand : {2, 4})   // the shortest bands that still fit the chip at once: most waves, least arithmetic per hand-shake
+                            // (bands of 8 rows — 144 registers of state — spill: 1M cells is the limit of this kernel)
+    if (c->p.ny % cand == 0 && c->p.ny / cand <= capacity) { bh = cand; break; }
+  if (bh == 0) return LBM_OK;
+  s.res_bh = bh;
+  s.res_w = W;
+  s.res_bands = c->p.ny / bh;
+  if (set_dev(s)) return LBM_ERR_HIP;
+  if (s.res_words) HIP_TRY(hipFree(s.res_words));
+  if (s.res_xrows) HIP_TRY(hipFree(s.res_xrows));
+  s.res_words = nullptr;
+  s.res_xrows = nullptr;
+  if (dev_alloc(&s.res_words, (size_t)s.res_bands * 32)) return LBM_ERR_HIP;
+  HIP_TRY(hipMemset(s.res_words, 0, (size_t)s.res_bands * 32 * sizeof(unsigned)));
+  if (dev_alloc(&s.res_xrows, (size_t)2 * s.res_bands * 2 * 3 * c->p.nx)) return LBM_ERR_HIP;
+  if (!s.res_err) {
+    if (dev_alloc(&s.res_err, 1)) return LBM_ERR_HIP;
+    HIP_TRY(hipMemset(s.res_err, 0, sizeof(unsigned)));
+  }
+  s.res_seq = 0;
+  s.nb_total = std::max(s.nb_total, s.res_bands * W);
+  return LBM_OK;
+}
 
 // LDS multi-step kernel: one slab holding the whole periodic grid; worth it only while the grid is launch-bound
 int multistep_effective(const lbm_ctx *c) {
@@ -1036,6 +1080,7 @@ int slab_geometry(const lbm_ctx *c, Slab &s) {
     }
     if (int rc = deep_geometry(c, s)) return rc;
   }
+  if (int rc = resident_geometry(c, s)) return rc;
   return LBM_OK;
 }
 
@@ -1329,6 +1374,44 @@ void launch_multi(const Slab &s, const MultiArgs &a, int tile_rows, hipStream_t 
   else hipLaunchKernelGGL((d2q9_multi<16, 8>), grid, block, 0, st, a);
 }
 
+template <int BH>
+void launch_resident_bh(const Slab &s, const ResidentArgs &a, hipStream_t st) {
+  const dim3 grid(s.res_bands);
+  switch (s.res_w) {
+    case 1: hipLaunchKernelGGL((d2q9_resident<BH, 1>), grid, dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((d2q9_resident<BH, 2>), grid, dim3(128), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((d2q9_resident<BH, 4>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((d2q9_resident<BH, 8>), grid, dim3(512), 0, st, a); break;
+  }
+}
+// `nsteps` timesteps in ONE launch (the caller keeps them within the ring of partial sums)
+void launch_resident(lbm_ctx *c, Slab &s, int src, int nsteps, bool accel_next, float *partials, hipStream_t st) {
+  ResidentArgs a{};
+  a.src = s.cells[src];
+  a.dst = s.cells[src ^ 1];
+  a.mask = s.mask;
+  a.partials = partials;
+  a.plane_stride = s.plane_stride;
+  a.row_stride = s.row_stride;
+  a.pstride = (unsigned long long)s.nb_total;
+  a.nx = c->p.nx;
+  a.ny = c->p.ny;
+  a.nsteps = nsteps;
+  a.accel_row = s.accel_ext;
+  a.accel_next = accel_next ? 1 : 0;
+  a.omega = c->p.omega;
+  a.aw1 = c->p.density * c->p.accel / 9.0f;
+  a.aw2 = c->p.density * c->p.accel / 36.0f;
+  a.words = s.res_words;
+  a.xrows = s.res_xrows;
+  a.seq_base = s.res_seq;
+  a.err = s.res_err;
+  a.wait_ticks = c->halo_timeout_ms * kTicksPerMs;
+  s.res_seq += (unsigned)nsteps + 1u;
+  if (s.res_bh == 2) launch_resident_bh<2>(s, a, st);
+  else launch_resident_bh<4>(s, a, st);
+}
+
 void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t st) {
   // Non-temporal stores always (a result is not read again before the next launch).  Source loads: HYBRID —
   // non-temporal (lower latency, no cache pollution) for the rows only this chunk reads, plain for the two
@@ -1526,7 +1609,8 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
   const bool deep_lvl = fuse_lvl >= kDeepMin || slab_twin5(c);  // the deep window kernels (slab_twin5: their five-step pairs in compact launch sets)
   const bool deep_twin = fuse_lvl >= kDeepMin && deep_twin_effective(c);
   int batch_first = c->steps_done;
-  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4, KIND_FUSED4 = 5, KIND_DEEP = 6 };
+  enum { KIND_NONE = 0, KIND_SINGLE = 1, KIND_FUSED2 = 2, KIND_MULTI = 3, KIND_FUSED3 = 4, KIND_FUSED4 = 5, KIND_DEEP = 6, KIND_RESIDENT = 7 };
+  const bool resident = resident_effective(c);
   int batch_kind = KIND_NONE;  // launch kind of the steps buffered in the ring (their slot occupancy differs)
   int last_q = 1;
   const int multi_T = multistep_effective(c);
@@ -1543,6 +1627,7 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       if (batch_kind == KIND_FUSED4) used = s.f4_main.units + (multi ? s.f_edge.units : 0);
       if (batch_kind == KIND_DEEP) used = deep_twin ? s.f6_twin.units : s.f6_main.units + (multi ? s.f6_edge.units : 0);
       if (batch_kind == KIND_MULTI) used = s.m_tiles_x * s.m_tiles_y;
+      if (batch_kind == KIND_RESIDENT) used = s.res_bands * s.res_w;
       hipLaunchKernelGGL(reduce_partials, dim3(fill), dim3(kBlock), 0, s.s_main, s.partials, s.nb_total, used,
                          s.av_sum + batch_first);
       HIP_TRY(hipGetLastError());
@@ -1568,7 +1653,11 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
     const int src = c->cur;
     // timesteps advanced by this launch set, and with which kernel
     int kind = KIND_SINGLE, adv = 1;
-    if (multi_T > 0) {
+    if (resident) {
+      // all remaining steps in one launch, as far as the ring of per-step partial sums reaches
+      kind = KIND_RESIDENT;
+      adv = std::min(nsteps - i, c->ring);
+    } else if (multi_T > 0) {
       kind = KIND_MULTI;
       adv = std::min(multi_T, nsteps - i);
     } else if (deep_lvl && nsteps - i >= 2) {
@@ -1601,7 +1690,9 @@ int run_steps_impl(lbm_ctx *c, int nsteps, bool timed, double *ms, bool *launche
       float *slot2 = slot1 + s.nb_total;
       if (!multi) {
         if (int rc = mark(s, 3, s.s_main)) return rc;
-        if (kind == KIND_MULTI) {
+        if (kind == KIND_RESIDENT) {
+          launch_resident(c, s, src, adv, !last, slot1, s.s_main);
+        } else if (kind == KIND_MULTI) {
           MultiArgs a = base_args_multi(c, s, src, adv, !last);
           a.partials = slot1;
           a.ty_begin = 0; a.ty_split = s.m_tiles_y; a.ty_begin2 = 0;
@@ -1901,6 +1992,15 @@ int sync_all(lbm_ctx *c) {
     if (set_dev(s)) return LBM_ERR_HIP;
     if (s.s_edge) HIP_TRY(hipStreamSynchronize(s.s_edge));
     HIP_TRY(hipStreamSynchronize(s.s_main));
+    if (s.res_err && s.res_seq != 0) {
+      unsigned err = 0;
+      HIP_TRY(hipMemcpy(&err, s.res_err, sizeof err, hipMemcpyDeviceToHost));
+      if (err) {
+        c->failed = true;
+        return fail(LBM_ERR_COMM, "d2q9_resident: a band waited %.3g s for its neighbour's rows (the workgroups were not all resident?)",
+                    (double)c->halo_timeout_ms * 1e-3);
+      }
+    }
     if (c->transport_eff == TRANSPORT_PEER && s.halo_flags) {
       uint32_t err = 0;
       HIP_TRY(hipMemcpy(&err, s.halo_flags + 2, sizeof err, hipMemcpyDeviceToHost));
@@ -1965,6 +2065,12 @@ void free_slab(Slab &s) {
     if (l->flags) hipIpcCloseMemHandle(l->flags);
   }
   if (s.halo_flags) hipFree(s.halo_flags);
+  if (s.res_words) hipFree(s.res_words);
+  if (s.res_xrows) hipFree(s.res_xrows);
+  if (s.res_err) hipFree(s.res_err);
+  s.res_words = nullptr;
+  s.res_xrows = nullptr;
+  s.res_err = nullptr;
   for (int k = 0; k < 2; k++)
     if (s.stage[k]) hipFree(s.stage[k]);
   if (s.d_stage_peer) hipFree(s.d_stage_peer);
@@ -2901,6 +3007,12 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
         if (int rc = upload_multi_peer(c, s)) return rc;
     return LBM_OK;
   }
+  if (!strcmp(key, "resident")) {
+    if (value < -1 || value > 1) return fail(LBM_ERR_ARG, "resident must be -1 (auto), 0 or 1");
+    if (int rc = sync_all(c)) return rc;
+    c->resident = (int)value;
+    return rebuild_geometry(c);
+  }
   if (!strcmp(key, "multistep")) {
     if (value < -1 || value > kMultiMaxT) return fail(LBM_ERR_ARG, "multistep must be -1..%d", kMultiMaxT);
     c->multistep = (int)value;
@@ -2929,7 +3041,8 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "grid_blocks")) *value = c->slabs.empty() ? 0 : c->slabs[0].nb_main;
   else if (!strcmp(key, "nt_stores")) *value = nt_effective(c);
   else if (!strcmp(key, "fuse")) *value = fuse_level(c) >= 3 ? fuse_level(c) : (fuse_level(c) ? 1 : 0);
-  else if (!strcmp(key, "multistep")) *value = multistep_effective(c);
+  else if (!strcmp(key, "multistep")) *value = resident_effective(c) ? 0 : multistep_effective(c);
+  else if (!strcmp(key, "resident")) *value = resident_effective(c) ? c->slabs[0].res_bh : 0;  // rows per band, 0 = not in use
   else if (!strcmp(key, "chunk_rows")) *value = c->chunk_rows;
   else if (!strcmp(key, "windows")) *value = windows_in_lds(c);
   else if (!strcmp(key, "pair")) *value = c->slabs.empty() ? 0 : slab_twin5(c) ? 1 : (fuse_level(c) >= kDeepMin ? (c->halo_mode ? (compact_sets(c) && c->slabs[0].f6_main.paired) : deep_twin_effective(c)) : fuse_level(c) == 4 ? c->slabs[0].f4_main.paired : c->slabs[0].f3_main.paired);

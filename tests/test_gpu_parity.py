@@ -119,6 +119,34 @@ def test_two_steps_per_launch_equals_single_steps(lbm, oracle_f32_omp, nx, ny, c
     assert max_rel(fused, ref) < RTOL_CELLS and max_rel(av_fused, av_ref) < RTOL_AV
 
 
+@pytest.mark.parametrize("nx,ny,bh", [(128, 6, 2), (128, 4, 2), (256, 64, 2), (512, 512, 2), (1024, 512, 2), (1024, 1024, 4), (512, 2048, 4), (128, 4100, 4)])
+@pytest.mark.parametrize("nsteps,split", [(1, 0), (2, 0), (7, 3), (23, 0), (300, 0)])
+def test_resident_kernel_equals_single_steps(lbm, nx, ny, bh, nsteps, split):
+    """d2q9_resident: all steps of an lbm_run in ONE launch with the grid in registers — bands of 2 or 4 full-width rows, one to
+    eight waves across, x neighbours through LDS, y neighbours through exchange rows in memory behind per-wave step words.
+    Random obstacles (open top and bottom rows: the y wrap between the last and the first band carries flow), an obstacle-free
+    band of rows (both collision paths), 300 steps = two launches (the ring of partial sums holds 256), split runs; the state
+    must equal single steps bit for bit"""
+    rng = np.random.default_rng(900 + nx + ny)
+    ob, cells0 = random_case(rng, nx, ny, blocked=0.06)
+    ob[0, :] = 0
+    ob[-1, :] = 0
+    ob[ny // 2: ny // 2 + max(1, ny // 8), :] = 0
+    p = lbm.make_params(nx, ny, nsteps, obstacles=ob)
+    one, av_one = run_gpu(lbm, p, ob, cells0, nsteps, SINGLE)
+    with lbm.LBM(p, ob) as sim:
+        sim.set_option("resident", 1)
+        assert sim.get_option("resident") == bh
+        sim.upload(cells0)
+        if split:
+            sim.run(split)
+            sim.sync()
+        sim.run(nsteps - split)
+        got, av = sim.download()
+    assert np.array_equal(one, got)
+    assert max_rel(av, av_one) < 2e-6
+
+
 @pytest.mark.parametrize("nx,ny", [(128, 128), (128, 256), (256, 256), (3, 3), (5, 4), (33, 17), (100, 70), (130, 31), (512, 48)])
 @pytest.mark.parametrize("T,nsteps", [(1, 3), (2, 7), (3, 8), (8, 8), (8, 21), (5, 16)])
 def test_lds_multistep_equals_single_steps(lbm, oracle_f32_omp, nx, ny, T, nsteps):
@@ -857,10 +885,10 @@ def test_abi_error_behaviour(lbm):
         with pytest.raises(lbm.LBMError):
             sim.set_option("variant", 9)
         # the options of the deep window kernel are range-checked like the others
-        for key, bad in (("fuse", 5), ("fuse", 9), ("twin_steps", 1), ("twin_steps", 9), ("obst_paths", 2), ("edge_aware", 2)):
+        for key, bad in (("fuse", -2), ("fuse", 9), ("twin_steps", 1), ("twin_steps", 9), ("obst_paths", 2), ("edge_aware", 2)):
             with pytest.raises(lbm.LBMError):
                 sim.set_option(key, bad)
-        for key, good in (("twin_steps", 0), ("twin_steps", 8), ("obst_paths", -1), ("edge_aware", -1), ("fuse", 7), ("fuse", -1)):
+        for key, good in (("twin_steps", 0), ("twin_steps", 8), ("obst_paths", -1), ("edge_aware", -1), ("fuse", 7), ("fuse", 5), ("fuse", -1)):
             sim.set_option(key, good)
         sim.set_option("twin_steps", 0)
         with pytest.raises(lbm.LBMError, match="max_iters"):
