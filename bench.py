@@ -440,7 +440,7 @@ def rank_leg(env, params, obstacles, transports, warmup, steps, fuse=-1, profile
                 before()      # the declared pre-warm-up (calibration launches), right before the W warm-up steps
             entry["wall_s"], entry["loop_ms"] = timed_run(env, sim, warmup, steps)
             entry["row_range"] = sim.row_range()
-            entry["options"] = {k: sim.get_option(k) for k in ("fuse", "pair", "launch_steps", "multistep", "halo_depth")}
+            entry["options"] = {k: sim.get_option(k) for k in OPTION_KEYS}
             if want_av:
                 entry["av"] = rs.av_vels()     # collective (RCCL all-reduce): every rank got here
             if profile:
@@ -516,11 +516,11 @@ def oracle_leg(env, label, p, ob, transports, nsteps, fault):
             ec, ea = max_rel(got[:, y0:y1], ref), max_rel(av, av_ref)
             del got
             ec, ea = max_over_ranks(env.dist, [ec, ea], env.device)
-            o = {k: rs.sim.get_option(k) for k in ("fuse", "pair", "launch_steps", "multistep", "halo_depth", "compact")}
+            o = {k: rs.sim.get_option(k) for k in OPTION_KEYS + ("compact",)}
             res = {"ok": bool(ec < 2e-5 and ea < 1e-4), "cells_max_rel": float("%.3g" % ec), "av_vels_max_rel": float("%.3g" % ea),
                    "halo_depth": o["halo_depth"], "exchanges": -(-nsteps // max(1, o["launch_steps"])),
-                   "kernel": ("d2q9_multi" if o["multistep"] else "d2q9_deep%s" % ("_twin" if o["pair"] else "") if o["fuse"] >= 6 else
-                              "d2q9_step%d%s" % (max(o["launch_steps"], 1), "p" if o["pair"] else "")) + (", compact launch sets" if o["compact"] else ", two streams")}
+                   "kernel": kernel_label(o).split(" (")[0] + (" x%d" % o["launch_steps"] if o["fuse"] >= 5 and not o["multistep"] else "") +
+                             (", compact launch sets" if o["compact"] else ", two streams")}
             if tr == "peer":
                 res["push_release"] = rs.sim.get_option("push_release")
         except TransportFailed as e:
@@ -670,13 +670,30 @@ def self_launch(args, argv):
     pool).  It STREAMS the child's output: every record line ({"metric"...) goes to stdout the moment rank 0 prints it — the
     headline record first, the full record last — everything else to stderr; the exit code is the child's."""
     import threading
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ, LBM_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                PYTHONUNBUFFERED="1")
     env.setdefault("OMP_NUM_THREADS", "8")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=env, start_new_session=True)
-    records = []
+    for attempt in (1, 2):
+        # (the port is free when free_port() looks and may be taken when the rendezvous store binds it a second later: the ONE
+        # failure that is tried again — with another port, announced on stderr — and only if no rank has printed anything yet)
+        rc, records, port_taken = self_launch_once(args, argv, env, threading)
+        if rc == 0 or not port_taken or records or attempt == 2:
+            break
+        print("bench.py: the rendezvous port was taken between probing and binding (EADDRINUSE); starting the ranks once more on another port",
+              file=sys.stderr, flush=True)
+    if rc != 0:
+        raise SystemExit("bench.py --gpus %d: the ranks started with torch.distributed.run exited with code %d (their messages are above)"
+                         % (args.gpus, rc))
+    if not records:
+        raise SystemExit("bench.py --gpus %d: rank 0 printed no result line" % args.gpus)
+
+
+def self_launch_once(args, argv, env, threading):
+    """one start of the ranks: (exit code, record lines relayed, did the rendezvous fail on a taken port)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, bufsize=1, env=env, start_new_session=True)
+    records, seen = [], {"eaddrinuse": False}
 
     def relay():
         for ln in proc.stdout:
@@ -685,6 +702,8 @@ def self_launch(args, argv):
                 records.append(ln)
                 print(ln, flush=True)
             else:
+                if "EADDRINUSE" in ln:
+                    seen["eaddrinuse"] = True
                 print(ln, file=sys.stderr, flush=True)
 
     th = threading.Thread(target=relay, daemon=True)
@@ -698,11 +717,7 @@ def self_launch(args, argv):
         raise SystemExit("bench.py --gpus %d: the ranks did not finish within %d s (%d record line(s) had been printed by then)"
                          % (args.gpus, args.launch_timeout, len(records)))
     th.join(timeout=30)
-    if proc.returncode != 0:
-        raise SystemExit("bench.py --gpus %d: the ranks started with torch.distributed.run exited with code %d (their messages are above)"
-                         % (args.gpus, proc.returncode))
-    if not records:
-        raise SystemExit("bench.py --gpus %d: rank 0 printed no result line" % args.gpus)
+    return proc.returncode, records, seen["eaddrinuse"]
 
 
 def roofline_of(nx, rows_local, steps, loop_ms, multistep, fused, deep, twin):
@@ -735,10 +750,24 @@ def roofline_of(nx, rows_local, steps, loop_ms, multistep, fused, deep, twin):
                                    "speed-up over a perfect one-step-per-launch kernel, not a bandwidth"}}
 
 
+OPTION_KEYS = ("fuse", "pair", "launch_steps", "multistep", "halo_depth", "resident")
+
+
+def kernel_label(o):
+    """name of the kernel a context runs, from its read-back options (OPTION_KEYS)"""
+    if o.get("resident"):
+        return "d2q9_resident (bands of %d rows held in registers over all timesteps of a launch)" % o["resident"]
+    if o["multistep"]:
+        return "d2q9_multi"
+    if o["fuse"] >= 5:   # 5: the five-step chunk pairs of row slabs of 300K to 3M cells (compact launch sets)
+        return "d2q9_deep%s" % ("_twin" if o["pair"] else "")
+    return KERNELS[{0: 0, 1: 2, 3: 3, 4: 4}[o["fuse"]]]
+
+
 def kernel_shape(opts):
     """(fused, deep, twin, multistep) from a context's read-back options"""
-    fused = {0: 0, 1: 2, 3: 3, 4: 4, 6: 6, 7: 7, 8: 8}[opts["fuse"]]   # timesteps per launch of the dominant kernel (0: one)
-    deep = fused >= 6
+    fused = {0: 0, 1: 2, 3: 3, 4: 4, 5: 5, 6: 6, 7: 7, 8: 8}[opts["fuse"]]   # timesteps per launch of the dominant kernel (0: one)
+    deep = fused >= 5
     twin = bool(deep and opts["pair"])   # d2q9_deep_twin (chunk pairs: up to five steps per launch below 3M cells, up to eight from there)
     if deep:
         fused = opts["launch_steps"]
@@ -885,7 +914,7 @@ def main():
             e = {}
             e["wall_s"], e["loop_ms"] = timed_run(env, sim, warmup, steps)
             e["row_range"] = sim.row_range()
-            e["options"] = {k: sim.get_option(k) for k in ("fuse", "pair", "launch_steps", "multistep", "halo_depth")}
+            e["options"] = {k: sim.get_option(k) for k in OPTION_KEYS}
             if want_av:
                 e["av"] = sim.download(cells=False)[1]
             if ndev > 1:
@@ -1078,8 +1107,7 @@ def main():
                 s2.sync()
                 w2 = time.perf_counter() - t1
                 f2 = s2.get_option("launch_steps")
-                k2 = "d2q9_deep%s" % ("_twin" if s2.get_option("pair") else "") if s2.get_option("fuse") >= 6 else (
-                    "d2q9_multi" if s2.get_option("multistep") else KERNELS[{0: 0, 1: 2, 3: 3, 4: 4}[s2.get_option("fuse")]])
+                k2 = kernel_label({k: s2.get_option(k) for k in OPTION_KEYS})
             out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat (both grids fit the 256 MiB Infinity Cache: "
                                        "these bytes come from cache, not HBM — profiles/r02_config3.txt)",
                            "value": round(1024 * 1024 * n2 / w2 / 1e6, 1), "unit": "MLUPS", "steps": n2, "us_per_step": round(ms2 / n2 * 1e3, 3),

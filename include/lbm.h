@@ -233,6 +233,13 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  peer stores — from about 650 rows per slab at 8192 cells a row)
  *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
  *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
+ *   "resident"     1 = run all timesteps of an lbm_run (up to 256 per launch: the ring of per-step sums) in ONE launch with the
+ *                  grid held in registers (d2q9_resident: bands of 2 or 4 full-width rows, one to eight waves across; neighbouring
+ *                  bands trade their edge rows through memory behind step words, bounded by "halo_timeout_ms") where the grid
+ *                  allows it — one slab without halo rows, nx = 128, 256, 512 or 1024, ny a multiple of the band height, all
+ *                  bands resident on the device at once (up to 1M cells on 256 CUs) —, 0 = never, -1 = auto: from 200K cells
+ *                  while "fuse" and "multistep" are on auto.  Reads back as the rows per band in use (0 = not in use).
+ *                  Bit-identical to single steps.  A band that waits in vain ends the run with LBM_ERR_COMM.
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)
  *   "chunk_min"    fewest rows per wave at the tapered end of the schedule (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)
@@ -260,9 +267,12 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "debug_stale_exchange"  TEST HOOK, n >= 1: the n-th halo exchange from now announces itself (flag words, events) but
  *                  delivers no rows — on every rank of the ring alike —, 0 = off; clears itself when it fires.  Exists so that the
  *                  checks above the library (bench.py: transport_check) can be shown to catch a transport that loses halo rows.
- *   "compact"      peer transport: -1/1 = one launch per launch set on one stream, its first workgroups — the edge tiles /
- *                  edge chunks — store the halo rows into the neighbours themselves (LDS-tile kernel, three- / four-step
- *                  kernels, deep window kernel); 0 = edge launch / interior launch / push kernel on two streams
+ *   "compact"      row slabs: -1/1 = one launch per launch set on one stream, its first workgroups — the edge tiles /
+ *                  edge chunks — store the halo rows into the neighbours themselves (peer transport: LDS-tile kernel, three- /
+ *                  four-step kernels, deep window kernel incl. its five-step chunk pairs on slabs of 300K to 3M cells) or, under
+ *                  the RCCL transport on slabs that run the deep window kernel, into staging blocks which the edge stream sends
+ *                  once the flag word of the launch's last edge wave is up (hipStreamWaitValue32: "staged" launch sets);
+ *                  0 = edge launch / interior launch / push kernel (or RCCL exchange) on two streams
  * Read-only through lbm_get_option: "nslabs", "fuse_units", "halo_depth", "launch_steps" (most timesteps one launch of
  * the context's main kernel advances).
  */

@@ -2294,11 +2294,12 @@ __device__ __forceinline__ float resident_load1(const float *p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-template <int BH, int W>
-__global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
-  static_assert(BH >= 2 && BH <= 4 && W >= 1 && W <= 8, "band shape");
-  // x exchange inside the band: [parity][wave][row][3]: east[.] = planes 1,5,8 of the wave's last cell, west[.] = 3,6,7 of its first
-  __shared__ float xe[2][W][BH][4], xw[2][W][BH][4];
+// OBST: the wave holds a blocked cell (the obstacle map does not change during a run).  The whole band loop exists in both forms and
+// the kernel chooses ABOVE it: chosen per row inside the loop, the compiler merged the two collision paths into one that carries
+// the bounce-back selects and copies every row's result into place (916 VALU instructions per step of four rows, 251 of them moves,
+// 154 selects; the obstacle-free loop below has 608).  Both forms meet the same barriers.
+template <int BH, int W, bool OBST>
+__device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)[2][W][BH][4], float (&xw)[2][W][BH][4]) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int band = blockIdx.x, nbands = gridDim.x;
@@ -2308,14 +2309,12 @@ __global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
   const int bdn = (band + nbands - 1) % nbands, bup = (band + 1) % nbands;
   v2f f[BH][9];
   uint32_t m[BH];
-  bool blocked[BH];  // wave-uniform: a blocked cell in this wave's part of the row
 #pragma unroll
   for (int r = 0; r < BH; r++) {
     const size_t row = (size_t)(band * BH + r);
 #pragma unroll
     for (int k = 0; k < 9; k++) f[r][k] = *reinterpret_cast<const v2f *>(a.src + row * rs + k * ps + xcol);
-    m[r] = (*reinterpret_cast<const uint32_t *>(a.mask + row * a.nx + (xcol & ~3)) >> ((xcol & 2) * 8)) & 0xffffu;
-    blocked[r] = __builtin_amdgcn_ballot_w64(m[r] != 0u) != 0ull;
+    m[r] = OBST ? (*reinterpret_cast<const uint32_t *>(a.mask + row * a.nx + (xcol & ~3)) >> ((xcol & 2) * 8)) & 0xffffu : 0u;
   }
   const size_t xr_dir = (size_t)3 * a.nx, xr_band = 2 * xr_dir, xr_par = (size_t)nbands * xr_band;
   // (a band's W step words share one 128-byte line: the three words a wave polls per side are one memory transaction)
@@ -2330,10 +2329,13 @@ __global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
     resident_store(base + xr_dir + 0 * a.nx, f[0][4]);
     resident_store(base + xr_dir + 1 * a.nx, f[0][7]);
     resident_store(base + xr_dir + 2 * a.nx, f[0][8]);
+  };
+  auto raise_word = [&](unsigned seq) __attribute__((always_inline)) {
     drain_stores();  // write-through stores: acknowledged = they have left this XCD
     if (lane == 0) __hip_atomic_store(my_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   publish(a.seq_base + 1u);
+  raise_word(a.seq_base + 1u);
   for (int s = 0; s < a.nsteps; s++) {
     const unsigned seq = a.seq_base + 1u + (unsigned)s;   // the neighbours' rows of the state this step starts from
     const int par = s & 1;
@@ -2370,7 +2372,7 @@ __global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
       g[8] = pair_from_west(north[2], n8w);
       const bool acc = accel_ok && (band * BH + r == a.accel_row);
       v2f t;
-      if (!blocked[r]) t = collide2<false>(g, 0u, a.omega, acc, a.aw1, a.aw2, o);
+      if constexpr (!OBST) t = collide2<false>(g, 0u, a.omega, acc, a.aw1, a.aw2, o);
       else t = collide2<true>(g, m[r], a.omega, acc, a.aw1, a.aw2, o);
       sum += t.x + t.y;
 #pragma unroll
@@ -2423,7 +2425,8 @@ __global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
     }
     collide_row(BH - 1, prev256, prev5w, prev6e, ha, a8w, a7e);
     if (s + 1 < a.nsteps) publish(seq + 1u);
-    const float tot = wave_sum(sum);
+    const float tot = wave_sum(sum);  // (between the stores and their drain: the reduction runs while the stores are acknowledged)
+    if (s + 1 < a.nsteps) raise_word(seq + 1u);
     if (lane == 0) a.partials[(size_t)s * a.pstride + band * W + w] = tot;
   }
 #pragma unroll
@@ -2432,6 +2435,21 @@ __global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
 #pragma unroll
     for (int k = 0; k < 9; k++) *reinterpret_cast<v2f *>(a.dst + row * rs + k * ps + xcol) = f[r][k];
   }
+}
+
+template <int BH, int W>
+__global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
+  static_assert(BH >= 2 && BH <= 4 && W >= 1 && W <= 8, "band shape");
+  // x exchange inside the band: [parity][wave][row][3]: east[.] = planes 1,5,8 of the wave's last cell, west[.] = 3,6,7 of its first
+  __shared__ float xe[2][W][BH][4], xw[2][W][BH][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int xcol = w * 128 + 2 * lane;
+  uint32_t any = 0;
+#pragma unroll
+  for (int r = 0; r < BH; r++)
+    any |= (*reinterpret_cast<const uint32_t *>(a.mask + (size_t)(blockIdx.x * BH + r) * a.nx + (xcol & ~3)) >> ((xcol & 2) * 8)) & 0xffffu;
+  if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) resident_band<BH, W, true>(a, xe, xw);
+  else resident_band<BH, W, false>(a, xe, xw);
 }
 
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------

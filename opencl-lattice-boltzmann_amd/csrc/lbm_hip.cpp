@@ -469,20 +469,35 @@ bool fuse_effective(const lbm_ctx *c) { return fuse_level(c) != 0; }
 
 // d2q9_resident: one slab without halo rows whose grid decomposes into bands of BH full-width rows x W = nx/128 waves that are
 // all resident at once (two waves per SIMD: 8 / W workgroups per CU); res_* are set by resident_geometry.
+// Auto: from 200K cells (same-box A/B, us/step, the library's other choice / resident, profiles/r04_resident.txt: 256x256 1.79 / 2.13,
+// 128x2048 4.25 / 2.5, 512x512 3.87 / 2.54, 1024x512 5.17 / 3.08, 512x2048 6.41 / 3.74, 1024x1024 5.80 / 3.81); the kernel's limit is
+// what fits the registers of the chip at two waves per SIMD: 1M cells on 256 CUs.
 bool resident_effective(const lbm_ctx *c) {
   if (c->halo_mode || c->slabs.size() != 1 || c->slabs[0].res_bands <= 0) return false;
-  return c->resident > 0;
+  if (c->resident >= 0) return c->resident > 0;
+  return c->fuse < 0 && c->multistep < 0 && (long)c->p.nx * c->p.ny >= 200L * 1024;
+}
+const void *resident_kernel(int bh, int w) {
+  if (bh == 2) return w == 1 ? (const void *)d2q9_resident<2, 1> : w == 2 ? (const void *)d2q9_resident<2, 2> : w == 4 ? (const void *)d2q9_resident<2, 4> : (const void *)d2q9_resident<2, 8>;
+  return w == 1 ? (const void *)d2q9_resident<4, 1> : w == 2 ? (const void *)d2q9_resident<4, 2> : w == 4 ? (const void *)d2q9_resident<4, 4> : (const void *)d2q9_resident<4, 8>;
 }
 int resident_geometry(const lbm_ctx *c, Slab &s) {
   s.res_bh = s.res_w = s.res_bands = 0;
   if (c->halo_mode || c->resident == 0 || c->p.nx % 128 != 0 || c->p.nx / 128 > 8) return LBM_OK;
   const int W = c->p.nx / 128;
   if (W != 1 && W != 2 && W != 4 && W != 8) return LBM_OK;
-  const int capacity = s.cus * (8 / W);
+  if (set_dev(s)) return LBM_ERR_HIP;
   int bh = 0;
-  for (int cand : {2, 4})   // the shortest bands that still fit the chip at once: most waves, least arithmetic per hand-shake
-                            // (bands of 8 rows — 144 registers of state — spill: 1M cells is the limit of this kernel)
-    if (c->p.ny % cand == 0 && c->p.ny / cand <= capacity) { bh = cand; break; }
+  for (int cand : {2, 4}) {  // the shortest bands that still fit the chip at once: most waves, least arithmetic per hand-shake
+                             // (bands of 8 rows — 144 registers of state — spill: 1M cells is the limit of this kernel)
+    if (c->p.ny % cand != 0) continue;
+    // every band must be resident at once (they wait for each other): what the runtime says a CU holds of this instantiation, capped
+    // at the two waves per SIMD the schedules of this library plan with
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resident_kernel(cand, W), 64 * W, 0));
+    const int capacity = s.cus * std::min(per_cu, 8 / W);
+    if (c->p.ny / cand <= capacity) { bh = cand; break; }
+  }
   if (bh == 0) return LBM_OK;
   s.res_bh = bh;
   s.res_w = W;
@@ -3050,7 +3065,7 @@ int lbm_get_option(const lbm_ctx *c, const char *key, long *value) {
   else if (!strcmp(key, "launch_steps")) {
     // most timesteps one launch (launch set) of the context's main kernel advances
     const int ms = multistep_effective(c), lvl = fuse_level(c);
-    *value = ms > 0 ? ms : slab_twin5(c) ? kDeepTwinDefault : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, twin_cap(c)) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
+    *value = resident_effective(c) ? c->ring : ms > 0 ? ms : slab_twin5(c) ? kDeepTwinDefault : (lvl >= kDeepMin ? (deep_twin_effective(c) ? std::min(lvl, twin_cap(c)) : lvl) : (lvl >= 3 ? lvl : (lvl ? 2 : 1)));
   }
   else if (!strcmp(key, "fuse_units")) *value = c->slabs.empty() ? 0 : ((fuse_level(c) >= kDeepMin || slab_twin5(c)) ? c->slabs[0].f6_main.units + c->slabs[0].f6_edge.units - c->slabs[0].f_edge.units : fuse_level(c) == 4 ? c->slabs[0].f4_main.units : (fuse_level(c) == 3 ? c->slabs[0].f3_main.units : c->slabs[0].f_main.units)) + c->slabs[0].f_edge.units;
   else if (!strcmp(key, "transport")) *value = c->transport_eff;

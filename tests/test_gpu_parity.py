@@ -176,13 +176,21 @@ def test_default_kernel_choice_by_grid_size(lbm):
     """auto policy: LDS multi-step kernel for launch-bound grids, two-step kernel in between, three- and four-step kernels
     for bandwidth-bound ones, the deep window kernel above 300K cells — as chunk pairs (d2q9_deep_twin), with up to five steps
     per launch below 3M cells and up to eight from there on; grids of fewer than 32 rows, which the deep kernel does not take, fall
-    back to the two- / three-step kernels"""
-    expect = {(128, 128): (8, 0, 8), (256, 256): (8, 0, 8), (512, 512): (8, 0, 8), (640, 512): (0, 8, 5), (768, 512): (0, 8, 5), (1024, 512): (0, 8, 5), (16384, 24): (0, 1, 2), (32768, 24): (0, 3, 3),
-              (768, 768): (0, 8, 5), (1024, 1024): (0, 8, 5), (1536, 1024): (0, 8, 5), (2048, 1024): (0, 8, 5), (2048, 2048): (0, 8, 8),
-              (3072, 2048): (0, 8, 8), (4096, 2048): (0, 8, 8), (8192, 1024): (0, 8, 8), (128, 8192): (0, 0, 1)}
-    for (nx, ny), (ms, fuse, per_launch) in expect.items():
+    back to the two- / three-step kernels; and, round 4, the resident kernel (all steps of a launch with the grid in registers)
+    from 200K to 1M cells where the grid is 128, 256, 512 or 1024 cells wide and its bands of 2 or 4 rows all fit the chip at once"""
+    expect = {(128, 128): (8, 0, 8), (256, 256): (8, 0, 8), (512, 512): "resident 2", (640, 512): (0, 8, 5), (768, 512): (0, 8, 5), (1024, 512): "resident 2",
+              (16384, 24): (0, 1, 2), (32768, 24): (0, 3, 3), (512, 384): (8, 0, 8),
+              (768, 768): (0, 8, 5), (1024, 1024): "resident 4", (1024, 1028): (0, 8, 5), (1536, 1024): (0, 8, 5), (2048, 1024): (0, 8, 5), (2048, 2048): (0, 8, 8),
+              (3072, 2048): (0, 8, 8), (4096, 2048): (0, 8, 8), (8192, 1024): (0, 8, 8), (128, 8192): "resident 4", (128, 8200): (0, 0, 1)}
+    for (nx, ny), want in expect.items():
         ob = np.zeros((ny, nx), np.int32)
         with lbm.LBM(lbm.make_params(nx, ny, 4, obstacles=ob), ob) as sim:
+            if isinstance(want, str):
+                assert sim.get_option("resident") == int(want.split()[1]) and sim.get_option("multistep") == 0, (nx, ny)
+                sim.run(4)
+                continue
+            ms, fuse, per_launch = want
+            assert sim.get_option("resident") == 0, (nx, ny)
             assert (sim.get_option("multistep"), sim.get_option("fuse") if not ms else 0) == (ms, fuse), (nx, ny)
             assert sim.get_option("launch_steps") == per_launch, (nx, ny)
             if fuse == 8:   # one slab without halo rows: the deep window kernel always runs as chunk pairs (d2q9_deep_twin)

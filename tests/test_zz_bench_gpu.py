@@ -45,12 +45,11 @@ def _checked(tc, transports):
         assert deep["ok"] and deep["cells_max_rel"] < 2e-5 and deep["av_vels_max_rel"] < 1e-4
         assert deep["halo_depth"] == 8 and deep["exchanges"] == 5 and deep["kernel"].startswith("d2q9_deep")
         assert dig["ok"] and len(dig["digest_rank0"]) == 32
-    # the deep leg ran the kernels the 8192x8192 leg of a multi-GPU run runs: chunk pairs with the in-kernel push over peer
-    # stores, the lone kernel on two streams over RCCL
-    if "peer" in transports:
-        assert tc["legs"]["deep"]["transports"]["peer"]["kernel"] == "d2q9_deep_twin, compact launch sets"
-    if "rccl" in transports:
-        assert tc["legs"]["deep"]["transports"]["rccl"]["kernel"] == "d2q9_deep, two streams"
+    # the deep leg ran the kernels the 8192x8192 leg of a multi-GPU run runs: chunk pairs with the in-kernel push, ONE launch per
+    # launch set — into the ring neighbours over peer stores, into the staging blocks the edge stream sends over RCCL (round 4)
+    for t in ("peer", "rccl"):
+        if t in transports:
+            assert tc["legs"]["deep"]["transports"][t]["kernel"] == "d2q9_deep_twin x8, compact launch sets"
 
 
 def test_bench_json_contract():
@@ -215,7 +214,8 @@ def test_bench_one_process_per_gpu_path_single_rank():
     assert r.returncode == 0, _bench_failure(r)
     j = _records(r, True)
     assert j["n_gpus"] == 1 and j["result_ok"] is True and j["value"] > 1000
-    assert j["roofline"]["steps_per_launch"] == 4   # 2048x1024 = 2M cells: four steps per launch, also with halo rows
+    # 2048x1024 = 2M cells with halo rows: the five-step chunk pairs over peer stores, the four-step kernel on two streams over RCCL
+    assert j["roofline"]["steps_per_launch"] == (5 if j["transport"] == "peer" else 4)
     # both halo transports were measured on the ring of one; per-rank launch-set timings explain the record
     assert set(j["transports"]) == {"peer", "rccl"} and j["transport"] in j["transports"] and j["rccl_world_size"] == 1
     pr = j["per_rank_launch_set_us"]
