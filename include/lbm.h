@@ -239,7 +239,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *                  allows it — one slab without halo rows, nx = 128, 256, 512 or 1024, ny a multiple of the band height, all
  *                  bands resident on the device at once (up to 1M cells on 256 CUs) —, 0 = never, -1 = auto: from 200K cells
  *                  while "fuse" and "multistep" are on auto.  Reads back as the rows per band in use (0 = not in use).
- *                  Bit-identical to single steps.  A band that waits in vain ends the run with LBM_ERR_COMM.
+ *                  Bit-identical to single steps.  A band that waits in vain ends the run with LBM_ERR_COMM.  Such a launch needs
+ *                  the whole device: the library orders the resident launches of all contexts of a process one behind the other;
+ *                  whatever else fills the device meanwhile (another process, a long kernel of the caller's) delays it.
  *   "chunk_rows"   most rows swept by one wave of the two-step kernel (0 = auto)
  *   "chunk_min"    fewest rows per wave at the tapered end of the schedule (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)

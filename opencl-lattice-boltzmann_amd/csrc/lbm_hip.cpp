@@ -1423,8 +1423,16 @@ void launch_resident(lbm_ctx *c, Slab &s, int src, int nsteps, bool accel_next, 
   a.err = s.res_err;
   a.wait_ticks = c->halo_timeout_ms * kTicksPerMs;
   s.res_seq += (unsigned)nsteps + 1u;
+  // A resident launch needs every band on the device at once: two of them running side by side (two contexts of this process on
+  // their own streams) would each hold CUs the other is waiting for, until the timeout.  One event per device orders them.
+  // (Another PROCESS on the same device is the caller's business, as is any long kernel of its own that fills the device.)
+  static hipEvent_t res_done[64] = {};
+  hipEvent_t &ev = res_done[s.dev & 63];
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+  if (ev) (void)hipStreamWaitEvent(st, ev, 0);
   if (s.res_bh == 2) launch_resident_bh<2>(s, a, st);
   else launch_resident_bh<4>(s, a, st);
+  if (ev) (void)hipEventRecord(ev, st);
 }
 
 void launch_step2(const lbm_ctx *c, const Step2Args &a, int units, hipStream_t st) {
