@@ -222,9 +222,10 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "free_sweeps"  deep window kernel at 6, 7, 8 timesteps per launch: 1 (and -1, auto) = a wave whose chunk of rows holds no
  *                  blocked cell inside its strip (looked up in a map built from the obstacle map) sweeps it without any
  *                  obstacle handling, 0 = every wave looks level by level ("obst_paths").  Same results bit for bit.
- *   "windows"      where the three-step kernel keeps its two windows: 1 = LDS (two waves per SIMD), 0 = registers
- *                  (one wave per SIMD), -1 = auto (1)
- *   "load_bufs"    row-sets of source loads the three-step kernel keeps in flight: 1 or 2, 0 = auto
+ *   "windows", "load_bufs"   kept for callers that set them: the three-step kernel exists in ONE form since round 4 — its two
+ *                  windows in LDS (two waves per SIMD), one row-set of source loads in flight; "windows" accepts -1 / 1,
+ *                  "load_bufs" 0 / 1 (the register-window form and the two-row-set form, 253-256 registers at one wave per
+ *                  SIMD, were measured slower in rounds 1-2 and no policy selected them)
  *   "sched_waves"  waves per SIMD the three- / four-step kernels' chunk schedule plans for: 1 or 2, 0 = auto
  *   "pair"         chunk-pair form of the three- / four-step kernels and of the deep window kernel (two chunks that start
  *                  at a common boundary run as one workgroup and hand each other their first rows instead of computing
@@ -246,10 +247,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "chunk_min"    fewest rows per wave at the tapered end of the schedule (0 = auto)
  *   "grid_blocks"  cap on workgroups per launch (0 = auto)
  *   "nt_stores"    1 = non-temporal stores for the destination grid, 0 = plain, -1 = auto
- *   "nt_loads"     source loads of the two- and three-step kernels: 0 = plain, 1 = non-temporal, 2 = non-temporal
- *                  except for the rows shared with the neighbouring chunk, -1 = auto (2 for the two-step kernel, 0 for
- *                  the three-step kernel with its windows in LDS).  The four-step kernel always loads plain (it has no
- *                  register to spare: its non-temporal forms spilled to scratch and were removed).
+ *   "nt_loads"     source loads of the two-step kernel: 0 = plain, 1 = non-temporal, 2 = non-temporal except for the rows shared
+ *                  with the neighbouring chunk, -1 = auto (2).  The three- and four-step kernels always load plain (with two waves
+ *                  per SIMD plain loads won at every size; the four-step kernel's non-temporal forms spilled and were removed).
  *   "transport"    halo transport of a context that carries halo rows: 1 = RCCL send/recv (needs a communicator),
  *                  3 = peer stores (needs connected peers); read-only values 2 = device-to-device copies, 0 = none yet
  *   "halo_sync"    peer transport, consumer side: 0 = wait kernel with a bounded spin (default), 1 = hipStreamWaitValue32

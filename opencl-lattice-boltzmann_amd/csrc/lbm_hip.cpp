@@ -559,7 +559,7 @@ bool compact_sets(const lbm_ctx *c) {
   if (multistep_effective(c) > 0) return true;
   const int lvl = fuse_level(c);
   if (lvl >= kDeepMin) return true;  // d2q9_deep<.., PUSH>
-  return (lvl == 3 || lvl == 4) && windows_in_lds(c) && step3_load_bufs(c) == 1 && c->nt_loads <= 0;
+  return (lvl == 3 || lvl == 4) && windows_in_lds(c) && step3_load_bufs(c) == 1;
 }
 
 // Work decomposition of d2q9_step2 over stored rows [r0, r1): strips x chunks.  A unit's cost is
@@ -1187,38 +1187,20 @@ Step2Args base_args2(const lbm_ctx *c, const Slab &s, int src, bool accel_next, 
   return a;
 }
 
-template <bool WLDS, int NBUF>
-void launch_step3_v(int ntl, const Step2Args &a, float *partials3, int units, hipStream_t st) {
-  const dim3 grid(units), block(64);
-  if (ntl == 2) hipLaunchKernelGGL((d2q9_step3<true, 2, WLDS, NBUF>), grid, block, 0, st, a, partials3);
-  else if (ntl == 1) hipLaunchKernelGGL((d2q9_step3<true, 1, WLDS, NBUF>), grid, block, 0, st, a, partials3);
-  else hipLaunchKernelGGL((d2q9_step3<true, 0, WLDS, NBUF>), grid, block, 0, st, a, partials3);
-}
-
+// d2q9_step3 in the ONE form that is left of it: windows in LDS (two waves per SIMD), one row-set of loads in flight, plain loads;
+// d2q9_step3p = its chunk pairs.  (Round 4 removed the register-window form, the form with two row-sets of loads in flight and the
+// non-temporal-load variants — nine instantiations at 253-256 registers that no policy selected: LDS windows 230 against 188 GLUPS on
+// 8192x8192, plain loads 227.6 against 221.4 hybrid / 202.3 non-temporal, tools/ab.py, rounds 1-2.)
 void launch_step3(const lbm_ctx *c, const Step2Args &a0, float *partials3, int units, hipStream_t st, bool paired = false) {
-  const bool lds = windows_in_lds(c);
+  (void)c;
   if (paired) {
     // one workgroup of two waves per pair of chunks: a.units_per_band counts pairs x strips
     Step2Args a = a0;
     a.units_per_band = a0.units_per_band / 2;
-    const int ntl = c->nt_loads >= 0 ? c->nt_loads : 0;
-    const dim3 grid(units / 2), block(128);
-    if (ntl == 2) hipLaunchKernelGGL((d2q9_step3p<true, 2>), grid, block, 0, st, a, partials3);
-    else if (ntl == 1) hipLaunchKernelGGL((d2q9_step3p<true, 1>), grid, block, 0, st, a, partials3);
-    else hipLaunchKernelGGL((d2q9_step3p<true, 0>), grid, block, 0, st, a, partials3);
+    hipLaunchKernelGGL((d2q9_step3p<true, 0>), dim3(units / 2), dim3(128), 0, st, a, partials3);
     return;
   }
-  const Step2Args &a = a0;
-  // source loads: with two waves per SIMD (LDS windows) plain loads win at every size — 8192x8192 227.6 against 221.4
-  // GLUPS with the hybrid scheme, 202.3 all non-temporal; 2048x2048 180.8 / 175.2 / 165.3; 1024x1024 117.9 / 116.4 /
-  // 106.0 (tools/ab.py) — the rows a chunk shares with its neighbours and the strips' edge lines stay in L2;
-  // with one wave per SIMD (register windows) the lower latency of the hybrid scheme was worth more
-  const int ntl = c->nt_loads >= 0 ? c->nt_loads : (lds ? 0 : 2);
-  const bool one = step3_load_bufs(c) == 1;
-  if (lds && one) launch_step3_v<true, 1>(ntl, a, partials3, units, st);
-  else if (lds) launch_step3_v<true, 2>(ntl, a, partials3, units, st);
-  else if (one) launch_step3_v<false, 1>(ntl, a, partials3, units, st);
-  else launch_step3_v<false, 2>(ntl, a, partials3, units, st);
+  hipLaunchKernelGGL((d2q9_step3<true, 0, true, 1>), dim3(units), dim3(64), 0, st, a0, partials3);
 }
 
 void launch_step4(const lbm_ctx *c, const Step2Args &a0, float *partials3, float *partials4, int units, hipStream_t st,
@@ -2960,6 +2942,9 @@ int lbm_set_option(lbm_ctx *c, const char *key, long value) {
   }
   if (!strcmp(key, "windows") || !strcmp(key, "load_bufs") || !strcmp(key, "sched_waves")) {
     if (value < -1 || value > 2) return fail(LBM_ERR_ARG, "%s out of range", key);
+    // (round 4: the three-step kernel exists with its windows in LDS and one row-set of loads in flight only)
+    if (key[0] == 'w' && value == 0) return fail(LBM_ERR_ARG, "windows 0 (register windows of d2q9_step3) was removed: -1 or 1");
+    if (key[0] == 'l' && value == 2) return fail(LBM_ERR_ARG, "load_bufs 2 (two row-sets of loads in flight in d2q9_step3) was removed: 0 or 1");
     if (int rc = sync_all(c)) return rc;
     (key[0] == 'w' ? c->windows : (key[0] == 'l' ? c->load_bufs : c->sched_waves)) = (int)value;
     return rebuild_geometry(c);
