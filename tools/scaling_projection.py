@@ -21,7 +21,7 @@ def rate(nx, rows, steps, ring):
         sim.upload(None); sim.run(48)
         ms = min(sim.run_timed(steps) for _ in range(3))
         f = sim.get_option("fuse")
-        kern = "multi x%d" % sim.get_option("multistep") if sim.get_option("multistep") else (
+        kern = "resident x%d" % sim.get_option("launch_steps") if sim.get_option("resident") else "multi x%d" % sim.get_option("multistep") if sim.get_option("multistep") else (
             "deep%s x%d" % ("_twin" if sim.get_option("pair") else "", sim.get_option("launch_steps")) if f >= 5 else {0: "step", 1: "step2", 3: "step3", 4: "step4"}[f])
     return ms / steps * 1e3, kern
 
