@@ -2297,7 +2297,7 @@ __device__ __forceinline__ float resident_load1(const float *p) {
 // OBST: the wave holds a blocked cell (the obstacle map does not change during a run).  The whole band loop exists in both forms and
 // the kernel chooses ABOVE it: chosen per row inside the loop, the compiler merged the two collision paths into one that carries
 // the bounce-back selects and copies every row's result into place (916 VALU instructions per step of four rows, 251 of them moves,
-// 154 selects; the obstacle-free loop below has 608).  Both forms meet the same barriers.
+// 154 selects; the obstacle-free loop below has 555).  Both forms meet the same barriers.
 template <int BH, int W, bool OBST>
 __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)[2][W][BH][4], float (&xw)[2][W][BH][4]) {
   const int lane = threadIdx.x & 63;

@@ -414,10 +414,20 @@ constexpr long kSlabTwinCells = 300L * 1024;
 constexpr int kOneRoundRows = 160;   // d2q9_deep: longest chunk of a one-round schedule (see deep_geometry)
 constexpr int kMaxHeavyStrips = 4;  // see build_clean_bits / balance_heavy_strips
 bool compact_transport(const lbm_ctx *c) { return c->halo_mode && c->transport_eff == TRANSPORT_PEER && c->compact != 0; }
+// RCCL contexts whose launch sets can be STAGED (see staged_sets): the edge stream must be able to wait on a flag word
+bool stageable_transport(const lbm_ctx *c) {
+  if (!c->halo_mode || c->transport_eff != TRANSPORT_RCCL || c->compact == 0 || c->slabs.empty()) return false;
+  for (const Slab &s : c->slabs)
+    if (!s.can_wait_value) return false;
+  return true;
+}
 // the slab form of the five-step chunk pairs (see kSlabTwinCells): five halo rows, compact launch sets, kernel choice left to the library
 bool slab_twin5(const lbm_ctx *c) {
   if ((long)c->p.nx * c->rows_min <= kSlabTwinCells || (long)c->p.nx * c->rows_min >= kSlabDeepCells) return false;
-  return compact_transport(c) && (c->halo_depth == kDeepTwinDefault || c->halo_depth == kMultiMaxT) && fuse_possible(c) && c->rows_min >= 4 * kDeepTwinDefault &&
+  // (over RCCL — staged launch sets — only where the five rows exchanged are the rows stored, i.e. above the LDS tiles' range: those
+  // slabs ran the three- / four-step kernels on two streams: 2048x1024 17.25 -> 13.08 us/step, 4096x512 18.09 -> 13.10, profiles/r04_staged_rccl.txt)
+  const bool transport_ok = compact_transport(c) || (stageable_transport(c) && c->halo_depth == kDeepTwinDefault);
+  return transport_ok && (c->halo_depth == kDeepTwinDefault || c->halo_depth == kMultiMaxT) && fuse_possible(c) && c->rows_min >= 4 * kDeepTwinDefault &&
          c->pair != 0 && c->multistep <= 0 && (c->fuse < 0 || c->fuse == kDeepTwinDefault) && c->twin_steps <= 0;
 }
 int twin_cap(const lbm_ctx *c) {
@@ -467,7 +477,7 @@ int fuse_level(const lbm_ctx *c) {
 }
 bool fuse_effective(const lbm_ctx *c) { return fuse_level(c) != 0; }
 
-// d2q9_resident: one slab without halo rows whose grid decomposes into bands of BH full-width rows x W = nx/128 waves that are
+// d2q9_resident: one slab without halo rows whose grid decomposes into bands of BH full-width rows x W = nx/128 <= 8 waves that are
 // all resident at once (two waves per SIMD: 8 / W workgroups per CU); res_* are set by resident_geometry.
 // Auto: from 200K cells (same-box A/B, us/step, the library's other choice / resident, profiles/r04_resident.txt: 256x256 1.79 / 2.13,
 // 128x2048 4.25 / 2.5, 512x512 3.87 / 2.54, 1024x512 5.17 / 3.08, 512x2048 6.41 / 3.74, 1024x1024 5.80 / 3.81); the kernel's limit is
@@ -477,15 +487,24 @@ bool resident_effective(const lbm_ctx *c) {
   if (c->resident >= 0) return c->resident > 0;
   return c->fuse < 0 && c->multistep < 0 && (long)c->p.nx * c->p.ny >= 200L * 1024;
 }
-const void *resident_kernel(int bh, int w) {
-  if (bh == 2) return w == 1 ? (const void *)d2q9_resident<2, 1> : w == 2 ? (const void *)d2q9_resident<2, 2> : w == 4 ? (const void *)d2q9_resident<2, 4> : (const void *)d2q9_resident<2, 8>;
-  return w == 1 ? (const void *)d2q9_resident<4, 1> : w == 2 ? (const void *)d2q9_resident<4, 2> : w == 4 ? (const void *)d2q9_resident<4, 4> : (const void *)d2q9_resident<4, 8>;
+template <int BH>
+const void *resident_kernel_bh(int w) {
+  switch (w) {
+    case 1: return (const void *)d2q9_resident<BH, 1>;
+    case 2: return (const void *)d2q9_resident<BH, 2>;
+    case 3: return (const void *)d2q9_resident<BH, 3>;
+    case 4: return (const void *)d2q9_resident<BH, 4>;
+    case 5: return (const void *)d2q9_resident<BH, 5>;
+    case 6: return (const void *)d2q9_resident<BH, 6>;
+    case 7: return (const void *)d2q9_resident<BH, 7>;
+    default: return (const void *)d2q9_resident<BH, 8>;
+  }
 }
+const void *resident_kernel(int bh, int w) { return bh == 2 ? resident_kernel_bh<2>(w) : resident_kernel_bh<4>(w); }
 int resident_geometry(const lbm_ctx *c, Slab &s) {
   s.res_bh = s.res_w = s.res_bands = 0;
   if (c->halo_mode || c->resident == 0 || c->p.nx % 128 != 0 || c->p.nx / 128 > 8) return LBM_OK;
   const int W = c->p.nx / 128;
-  if (W != 1 && W != 2 && W != 4 && W != 8) return LBM_OK;
   if (set_dev(s)) return LBM_ERR_HIP;
   int bh = 0;
   for (int cand : {2, 4}) {  // the shortest bands that still fit the chip at once: most waves, least arithmetic per hand-shake
@@ -547,10 +566,8 @@ int multistep_effective(const lbm_ctx *c) {
 // for that exchange's event.  Two-stream sets (edge launch + interior launch of the lone kernel) ran the 8192x1024 slab at 335 GLUPS per
 // rank against 404 over peer stores; option "compact" 0 brings them back.
 bool staged_sets(const lbm_ctx *c) {
-  if (!c->halo_mode || c->transport_eff != TRANSPORT_RCCL || c->compact == 0 || c->slabs.empty()) return false;
-  for (const Slab &s : c->slabs)
-    if (!s.can_wait_value) return false;
-  return multistep_effective(c) == 0 && fuse_level(c) >= kDeepMin;
+  if (!stageable_transport(c)) return false;
+  return multistep_effective(c) == 0 && (fuse_level(c) >= kDeepMin || slab_twin5(c));
 }
 bool compact_sets(const lbm_ctx *c) {
   if (staged_sets(c)) return true;
@@ -1377,7 +1394,11 @@ void launch_resident_bh(const Slab &s, const ResidentArgs &a, hipStream_t st) {
   switch (s.res_w) {
     case 1: hipLaunchKernelGGL((d2q9_resident<BH, 1>), grid, dim3(64), 0, st, a); break;
     case 2: hipLaunchKernelGGL((d2q9_resident<BH, 2>), grid, dim3(128), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((d2q9_resident<BH, 3>), grid, dim3(192), 0, st, a); break;
     case 4: hipLaunchKernelGGL((d2q9_resident<BH, 4>), grid, dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((d2q9_resident<BH, 5>), grid, dim3(320), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((d2q9_resident<BH, 6>), grid, dim3(384), 0, st, a); break;
+    case 7: hipLaunchKernelGGL((d2q9_resident<BH, 7>), grid, dim3(448), 0, st, a); break;
     default: hipLaunchKernelGGL((d2q9_resident<BH, 8>), grid, dim3(512), 0, st, a); break;
   }
 }

@@ -20,7 +20,10 @@ if transport == "rccl_deep":
     # units store their rows into the slab's staging blocks; the edge stream waits on the flag word (hipStreamWaitValue32), sends the
     # blocks to itself and receives into the halo rows beside the running interior.  23 steps = 8 + 8 + 7; the two-stream form
     # ("compact" 0); split runs; and the test hook: an exchange that delivers nothing must change the result
-    nx, ny, nsteps = 8192, 416, 23
+    # (second case: a slab of 1.2M cells — five halo rows, the five-step chunk pairs with their edge pairs, staged the same way)
+    big = len(sys.argv) < 3 or sys.argv[2] != "twin5"
+    nx, ny, nsteps = (8192, 416, 23) if big else (2048, 700, 23)
+    want_fuse, want_halo = (8, 8) if big else (5, 5)
     ob = (rng.random((ny, nx)) < 0.0002).astype(np.int32)
     ob[0, :] = ob[-1, :] = 0
     ob[:, 0] = ob[:, -1] = 1
@@ -40,8 +43,13 @@ if transport == "rccl_deep":
         with lbm_amd.LBM(p, ob, rank=0, nranks=1, device=0, comm=lbm_amd.comm_id()) as sim:
             sim.set_option("compact", compact)
             sim.set_option("pair", pair)
-            assert sim.get_option("transport") == 1 and sim.get_option("fuse") == 8 and sim.get_option("halo_depth") == 8
-            assert sim.get_option("compact") == (1 if compact else 0) and sim.get_option("pair") == (1 if compact and pair else 0)
+            assert sim.get_option("transport") == 1 and sim.get_option("halo_depth") == want_halo
+            if big:
+                assert sim.get_option("fuse") == 8
+                assert sim.get_option("compact") == (1 if compact else 0) and sim.get_option("pair") == (1 if compact and pair else 0)
+            else:   # the five-step pairs exist as staged sets only: without "compact" or "pair" the four-step kernel on two streams
+                on = bool(compact and pair)
+                assert sim.get_option("fuse") == (5 if on else 4) and sim.get_option("compact") == (1 if on else 0)
             if stale:
                 sim.set_option("debug_stale_exchange", stale)
             sim.upload(cells0)
@@ -50,7 +58,7 @@ if transport == "rccl_deep":
                 sim.sync()
             sim.run(nsteps - split)
             got, av = sim.download()
-        tag = "rccl staged sets: compact %d pair %d split %d stale %d" % (compact, pair, split, stale)
+        tag = "rccl staged sets (%dx%d): compact %d pair %d split %d stale %d" % (nx, ny, compact, pair, split, stale)
         same = np.array_equal(got, ref)
         if stale:
             assert not same, tag + ": a lost exchange went unnoticed"

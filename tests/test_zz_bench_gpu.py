@@ -214,14 +214,14 @@ def test_bench_one_process_per_gpu_path_single_rank():
     assert r.returncode == 0, _bench_failure(r)
     j = _records(r, True)
     assert j["n_gpus"] == 1 and j["result_ok"] is True and j["value"] > 1000
-    # 2048x1024 = 2M cells with halo rows: the five-step chunk pairs over peer stores, the four-step kernel on two streams over RCCL
-    assert j["roofline"]["steps_per_launch"] == (5 if j["transport"] == "peer" else 4)
+    # 2048x1024 = 2M cells with halo rows: the five-step chunk pairs, one launch per launch set — over peer stores and (staged) over RCCL
+    assert j["roofline"]["steps_per_launch"] == 5
     # both halo transports were measured on the ring of one; per-rank launch-set timings explain the record
     assert set(j["transports"]) == {"peer", "rccl"} and j["transport"] in j["transports"] and j["rccl_world_size"] == 1
     pr = j["per_rank_launch_set_us"]
     assert len(pr) == 1 and pr[0]["sets"] >= 4 and pr[0]["interior_us"] > 0 and pr[0]["set_period_us"] > 0
-    # (peer stores: compact launch sets, ONE launch per set, reported as the interior launch; RCCL: edge launch + exchange beside it)
-    assert pr[0]["transport"] == j["transport"] and (pr[0]["edge_us"] > 0) == (j["transport"] == "rccl")
+    # (compact launch sets under both transports: ONE launch per set, reported as the interior launch; no separate edge launch)
+    assert pr[0]["transport"] == j["transport"] and pr[0]["edge_us"] == 0
     # and the reference's 1024x1024 input row-partitioned over the same ranks (BASELINE config 4's leg of a multi-GPU record)
     assert j["also"]["value"] > 1000 and j["also"]["halo_depth"] >= 3 and len(j["also"]["per_rank_launch_set_us"]) == 1
     # before any timing every transport reproduced the oracle on the 1024x1024 obstacles from a random state (a transport
