@@ -330,6 +330,10 @@ class RankSim:
         self.env = env
         self.transport = transport
         self.error = None
+        if transport == "rccl2":
+            # RCCL with the launch sets of round 3: edge launch + exchange + interior launch on two streams (option "compact" 0) — the
+            # form main() falls back to when the staged launch sets (one launch per set, exchange behind a stream wait-value) fail a check
+            self.sim.set_option("compact", 0)
         if transport == "peer":
             size = lbm_amd.load_library().lbm_peer_info_size()
             try:
@@ -465,11 +469,17 @@ def max_rel(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)))
 
 
-def fault_legs():
-    """TEST HOOK: LBM_BENCH_FAULT=stale_halo[@leg,leg] makes one halo exchange of the named check legs ("small", "deep",
-    "digest"; none named = all three) deliver nothing (library option debug_stale_exchange) — the checks must catch it"""
+def fault_legs(transport=None):
+    """TEST HOOK: LBM_BENCH_FAULT=stale_halo[@leg,leg][:transport] makes one halo exchange of the named check legs ("small",
+    "deep", "digest"; none named = all three) deliver nothing (library option debug_stale_exchange) — the checks must catch it;
+    with `:transport` only the contexts of that transport are hit (how the fall-back from staged to two-stream RCCL sets is tested)"""
     f = os.environ.get("LBM_BENCH_FAULT", "")
     if not f.startswith("stale_halo"):
+        return set()
+    only = None
+    if ":" in f:
+        f, only = f.rsplit(":", 1)
+    if transport is not None and only is not None and transport != only:
         return set()
     return set(f.split("@", 1)[1].split(",")) if "@" in f else {"small", "deep", "digest"}
 
@@ -506,7 +516,7 @@ def oracle_leg(env, label, p, ob, transports, nsteps, fault):
         try:
             rs = RankSim(env, p, ob, tr)
             assert rs.sim.row_range() == (y0, y1)
-            if fault:
+            if fault and label in fault_legs(tr):
                 rs.sim.set_option("debug_stale_exchange", 3)
             upload_rows(rs.sim, nx, ny, y0, y1, state0)
             rs.sim.run(nsteps)
@@ -564,7 +574,7 @@ def digest_leg(env, params, obstacles, transports, nsteps, fault):
         rs, res = None, {}
         try:
             rs = RankSim(env, params, obstacles, tr)
-            if fault:
+            if fault and "digest" in fault_legs(tr):
                 rs.sim.set_option("debug_stale_exchange", 3)
             upload_rows(rs.sim, nx, ny, y0, y1, state0)
             rs.sim.run(nsteps)
@@ -621,8 +631,8 @@ def transport_check(env, params, obstacles, transports):
     reference's 1024x1024 obstacles for 400 steps (>= 50 exchanges of up to 8 halo rows; at 8 GPUs 128-row slabs on the
     LDS-tile kernel and its edge-tile push), `deep` — 8192 x 768N cells with side walls for 40 steps (slabs of 6M cells: the
     deep window kernels in the form the 8192x8192 leg runs them at 4 and 8 GPUs — one round of chunk pairs with push_chunk_pairs
-    and the per-wave publisher over peer stores, the lone kernel on two streams over RCCL —, five exchanges of 8 rows; the record
-    names the kernel that ran), both against the oracle; `digest` — the timed geometry, 32 steps,
+    and the per-wave publisher over peer stores, the same launch with staging blocks and a stream wait-value over RCCL ("rccl2": the
+    lone kernel on two streams) —, five exchanges of 8 rows; the record names the kernel that ran), both against the oracle; `digest` — the timed geometry, 32 steps,
     bit for bit.  A transport is `ok` only if it passed all three."""
     lbm_amd = env.lbm
     faults = fault_legs()
@@ -967,6 +977,17 @@ def main():
         log("checking transports %s on %d rank(s) before anything is timed" % (want, world), rank)
         tcheck = transport_check(env, params, obstacles, want)
         transports = [t for t in want if tcheck["transports"][t]["ok"]]
+        if "rccl" in want and "rccl" not in transports:
+            # RCCL's launch sets are "staged" since round 4 (one launch per set, the exchange behind hipStreamWaitValue32): a form that,
+            # like everything here, has met one device only.  Should it fail on the machine at hand, the two-stream sets of round 3
+            # (option "compact" 0) get the same three checks and take its place.
+            log("rccl (staged launch sets) failed %s: checking its two-stream form (rccl2)" % tcheck["transports"]["rccl"].get("failed_legs"), rank)
+            t2 = transport_check(env, params, obstacles, ["rccl2"])
+            tcheck["transports"]["rccl2"] = t2["transports"]["rccl2"]
+            for k in t2["legs"]:
+                tcheck["legs"][k]["transports"]["rccl2"] = t2["legs"][k]["transports"]["rccl2"]
+            if t2["transports"]["rccl2"]["ok"]:
+                transports.append("rccl2")
         log("transports that passed: %s" % transports, rank)
 
     # ---- the timed region(s): one per halo transport, the faster one is reported as `value` -----------------------

@@ -272,8 +272,9 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "compact"      row slabs: -1/1 = one launch per launch set on one stream, its first workgroups — the edge tiles /
  *                  edge chunks — store the halo rows into the neighbours themselves (peer transport: LDS-tile kernel, three- /
  *                  four-step kernels, deep window kernel incl. its five-step chunk pairs on slabs of 300K to 3M cells) or, under
- *                  the RCCL transport on slabs that run the deep window kernel, into staging blocks which the edge stream sends
- *                  once the flag word of the launch's last edge wave is up (hipStreamWaitValue32: "staged" launch sets);
+ *                  the RCCL transport on slabs that run the deep window kernel (from 3M cells) or its five-step chunk pairs
+ *                  (540K to 3M cells), into staging blocks which the edge stream sends once the flag word of the launch's last
+ *                  edge wave is up (hipStreamWaitValue32: "staged" launch sets);
  *                  0 = edge launch / interior launch / push kernel (or RCCL exchange) on two streams
  * Read-only through lbm_get_option: "nslabs", "fuse_units", "halo_depth", "launch_steps" (most timesteps one launch of
  * the context's main kernel advances).

@@ -241,7 +241,7 @@ struct Slab {
   uint32_t *halo_flags = nullptr;
   PeerLink south, north;
   lbm::HaloPeer *d_peer = nullptr;   // device copy of what the fused push / wait of d2q9_multi needs (filled when the ring is connected)
-  // staged launch sets (RCCL transport + the deep window kernel, staged_sets): the edge units of the ONE launch store their rows a second
+  // staged launch sets (RCCL transport + the deep window kernels, staged_sets): the edge units of the ONE launch store their rows a second
   // time into these two blocks of halo-depth rows (write-through, as into a peer's halo rows) and the last edge wave raises halo_flags[4]
   // and [5]; the edge stream waits on those words and sends from the blocks
   float *stage[2] = {nullptr, nullptr};
@@ -559,7 +559,8 @@ int multistep_effective(const lbm_ctx *c) {
 // tiles / edge chunks, which store the halo rows into the ring neighbours themselves and raise their flag words — instead
 // of edge launch + push kernel on an edge stream beside the interior launch.  For the LDS-tile kernel and for the
 // three- / four-step kernels in their default form (LDS windows, one row-set of loads in flight, plain loads).
-// Staged launch sets: the compact launch form under the RCCL transport, for slabs that run the deep window kernel.  ONE launch per
+// Staged launch sets: the compact launch form under the RCCL transport, for slabs that run the deep window kernel (8 halo rows) or its
+// five-step chunk pairs (5 halo rows: slab_twin5).  ONE launch per
 // set on the main stream — edge units first, chunk pairs, balanced: the kernel and schedule of the peer transport — whose edge units
 // push their rows into a local staging block instead of a neighbour; the edge stream waits for the flag word the last edge wave raises
 // (hipStreamWaitValue32), sends the blocks and receives into the halo rows while the interior is still running, and the next launch waits

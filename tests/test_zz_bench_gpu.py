@@ -180,6 +180,30 @@ def test_bench_transport_check_catches_a_stale_halo(legs):
     assert d["ok"] == ("digest" not in legs) and (("ranks_that_differ" in d) == ("digest" in legs))
 
 
+def test_bench_falls_back_from_staged_to_two_stream_rccl_sets():
+    """RCCL's launch sets are staged since round 4 (one launch per set, edge units push into staging blocks, the exchange behind a
+    stream wait-value).  If that form fails a check on the machine at hand, bench.py puts the two-stream sets of round 3 ("rccl2":
+    option compact 0) through the same three checks and times those instead.  Rehearsed on the RCCL ring of one with a lost
+    exchange injected into the staged contexts only"""
+    import json
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LBM_BENCH_RANK_MODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LBM_BENCH_FAULT="stale_halo@deep:rccl")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "24", "--warmup", "8", "--nx", "8192", "--ny", "1024", "--transport", "rccl",
+                        "--no-cpu-baseline", "--no-extra", "--no-cold"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, _bench_failure(r)
+    j = _records(r, True)
+    tc = j["transport_check"]
+    assert tc["transports"]["rccl"]["ok"] is False and tc["transports"]["rccl"]["failed_legs"] == ["deep"]
+    assert tc["transports"]["rccl2"]["ok"] is True and tc["legs"]["deep"]["transports"]["rccl2"]["kernel"] == "d2q9_deep x8, two streams"
+    assert set(j["transports"]) == {"rccl2"} and j["transport"] == "rccl2" and j["value"] > 1000 and j["result_ok"] is True
+
+
 def test_bench_one_process_form_rehearsal():
     """--launcher one-process: ONE process drives N row slabs (lbm_create(ndev = N)) — the form
     bench.py falls back to where torch.distributed.run is missing; rehearsed with 4 slabs on the one GPU"""
