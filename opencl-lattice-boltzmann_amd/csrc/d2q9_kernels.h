@@ -2298,8 +2298,9 @@ __device__ __forceinline__ float resident_load1(const float *p) {
 // the kernel chooses ABOVE it: chosen per row inside the loop, the compiler merged the two collision paths into one that carries
 // the bounce-back selects and copies every row's result into place (916 VALU instructions per step of four rows, 251 of them moves,
 // 154 selects; the obstacle-free loop below has 555).  Both forms meet the same barriers.
-template <int BH, int W, bool OBST>
-__device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)[2][W][BH][4], float (&xw)[2][W][BH][4]) {
+template <int BH, bool OBST>
+__device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)[2][8][BH][4], float (&xw)[2][8][BH][4]) {
+  const int W = (int)(blockDim.x >> 6);   // waves across the band = nx / 128 (1 .. 8): a launch parameter, not a template one
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int band = blockIdx.x, nbands = gridDim.x;
@@ -2437,19 +2438,19 @@ __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)
   }
 }
 
-template <int BH, int W>
-__global__ __launch_bounds__(64 * W) void d2q9_resident(const ResidentArgs a) {
-  static_assert(BH >= 2 && BH <= 4 && W >= 1 && W <= 8, "band shape");
+template <int BH>
+__global__ __launch_bounds__(512) void d2q9_resident(const ResidentArgs a) {
+  static_assert(BH >= 2 && BH <= 4, "band shape");
   // x exchange inside the band: [parity][wave][row][3]: east[.] = planes 1,5,8 of the wave's last cell, west[.] = 3,6,7 of its first
-  __shared__ float xe[2][W][BH][4], xw[2][W][BH][4];
+  __shared__ float xe[2][8][BH][4], xw[2][8][BH][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int xcol = w * 128 + 2 * lane;
   uint32_t any = 0;
 #pragma unroll
   for (int r = 0; r < BH; r++)
     any |= (*reinterpret_cast<const uint32_t *>(a.mask + (size_t)(blockIdx.x * BH + r) * a.nx + (xcol & ~3)) >> ((xcol & 2) * 8)) & 0xffffu;
-  if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) resident_band<BH, W, true>(a, xe, xw);
-  else resident_band<BH, W, false>(a, xe, xw);
+  if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) resident_band<BH, true>(a, xe, xw);
+  else resident_band<BH, false>(a, xe, xw);
 }
 
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------

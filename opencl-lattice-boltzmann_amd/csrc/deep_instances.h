@@ -27,9 +27,8 @@
   X(d2q9_deep_twin<5, true, true, 0, false>) X(d2q9_deep_twin<5, true, false, 0, false>)                             \
   X(d2q9_deep_twin<5, false, true, 0, false>) X(d2q9_deep_twin<5, false, false, 0, false>)                           \
   /* ... compact launch sets of row slabs of 240K to 3M cells (five halo rows): interior chunk pairs + edge chunk pairs */ \
-  X(d2q9_deep_twin<5, false, true, 5, true>) X(d2q9_deep_twin<5, true, true, 5, true>)                               \
-  X(d2q9_deep_twin<5, false, true, 0, true>) X(d2q9_deep_twin<5, true, true, 0, true>)                               \
-  X(d2q9_deep_twin<5, false, false, 0, true>) X(d2q9_deep_twin<5, true, false, 0, true>)                             \
+  X(d2q9_deep_twin<5, false, true, 5, true>) X(d2q9_deep_twin<5, false, true, 0, true>)                              \
+  X(d2q9_deep_twin<5, false, false, 0, true>)                                                                        \
   /* ... one slab, up to eight (from 3M cells) */                                                                    \
   X(d2q9_deep_twin<8, true, true, 8, false>) X(d2q9_deep_twin<8, true, true, 7, false>)                              \
   X(d2q9_deep_twin<8, true, true, 6, false>) X(d2q9_deep_twin<8, true, true, 0, false>)                              \

@@ -487,20 +487,7 @@ bool resident_effective(const lbm_ctx *c) {
   if (c->resident >= 0) return c->resident > 0;
   return c->fuse < 0 && c->multistep < 0 && (long)c->p.nx * c->p.ny >= 200L * 1024;
 }
-template <int BH>
-const void *resident_kernel_bh(int w) {
-  switch (w) {
-    case 1: return (const void *)d2q9_resident<BH, 1>;
-    case 2: return (const void *)d2q9_resident<BH, 2>;
-    case 3: return (const void *)d2q9_resident<BH, 3>;
-    case 4: return (const void *)d2q9_resident<BH, 4>;
-    case 5: return (const void *)d2q9_resident<BH, 5>;
-    case 6: return (const void *)d2q9_resident<BH, 6>;
-    case 7: return (const void *)d2q9_resident<BH, 7>;
-    default: return (const void *)d2q9_resident<BH, 8>;
-  }
-}
-const void *resident_kernel(int bh, int w) { return bh == 2 ? resident_kernel_bh<2>(w) : resident_kernel_bh<4>(w); }
+const void *resident_kernel(int bh) { return bh == 2 ? (const void *)d2q9_resident<2> : (const void *)d2q9_resident<4>; }
 int resident_geometry(const lbm_ctx *c, Slab &s) {
   s.res_bh = s.res_w = s.res_bands = 0;
   if (c->halo_mode || c->resident == 0 || c->p.nx % 128 != 0 || c->p.nx / 128 > 8) return LBM_OK;
@@ -513,7 +500,7 @@ int resident_geometry(const lbm_ctx *c, Slab &s) {
     // every band must be resident at once (they wait for each other): what the runtime says a CU holds of this instantiation, capped
     // at the two waves per SIMD the schedules of this library plan with
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resident_kernel(cand, W), 64 * W, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resident_kernel(cand), 64 * W, 0));
     const int capacity = s.cus * std::min(per_cu, 8 / W);
     if (c->p.ny / cand <= capacity) { bh = cand; break; }
   }
@@ -1274,16 +1261,10 @@ void launch_deep_compact(const lbm_ctx *c, const Slab &s, const Step2Args &a0, f
     a.edge_units = 4 * s.strips_tw;            // edge WAVES
     const dim3 pgrid(2 * s.strips_tw + s.f6_main.units / 2), pblock(128);
     constexpr int D5 = kDeepTwinDefault;
-    if (paths && c->steady != 0 && nlev == D5) {
-      if (nt) hipLaunchKernelGGL((d2q9_deep_twin<D5, true, true, D5, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
-      else hipLaunchKernelGGL((d2q9_deep_twin<D5, false, true, D5, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
-    } else if (paths) {
-      if (nt) hipLaunchKernelGGL((d2q9_deep_twin<D5, true, true, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
-      else hipLaunchKernelGGL((d2q9_deep_twin<D5, false, true, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
-    } else {
-      if (nt) hipLaunchKernelGGL((d2q9_deep_twin<D5, true, false, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
-      else hipLaunchKernelGGL((d2q9_deep_twin<D5, false, false, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
-    }
+    // (plain stores only: both grids of a slab of this size fit the Infinity Cache up to 2.8M cells; no non-temporal instantiations)
+    if (paths && c->steady != 0 && nlev == D5) hipLaunchKernelGGL((d2q9_deep_twin<D5, false, true, D5, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    else if (paths) hipLaunchKernelGGL((d2q9_deep_twin<D5, false, true, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
+    else hipLaunchKernelGGL((d2q9_deep_twin<D5, false, false, 0, true>), pgrid, pblock, 0, st, a, partials, s.nb_total, nlev);
     return;
   }
   if (s.f6_main.paired) {
@@ -1389,20 +1370,6 @@ void launch_multi(const Slab &s, const MultiArgs &a, int tile_rows, hipStream_t 
   else hipLaunchKernelGGL((d2q9_multi<16, 8>), grid, block, 0, st, a);
 }
 
-template <int BH>
-void launch_resident_bh(const Slab &s, const ResidentArgs &a, hipStream_t st) {
-  const dim3 grid(s.res_bands);
-  switch (s.res_w) {
-    case 1: hipLaunchKernelGGL((d2q9_resident<BH, 1>), grid, dim3(64), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((d2q9_resident<BH, 2>), grid, dim3(128), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((d2q9_resident<BH, 3>), grid, dim3(192), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((d2q9_resident<BH, 4>), grid, dim3(256), 0, st, a); break;
-    case 5: hipLaunchKernelGGL((d2q9_resident<BH, 5>), grid, dim3(320), 0, st, a); break;
-    case 6: hipLaunchKernelGGL((d2q9_resident<BH, 6>), grid, dim3(384), 0, st, a); break;
-    case 7: hipLaunchKernelGGL((d2q9_resident<BH, 7>), grid, dim3(448), 0, st, a); break;
-    default: hipLaunchKernelGGL((d2q9_resident<BH, 8>), grid, dim3(512), 0, st, a); break;
-  }
-}
 // `nsteps` timesteps in ONE launch (the caller keeps them within the ring of partial sums)
 void launch_resident(lbm_ctx *c, Slab &s, int src, int nsteps, bool accel_next, float *partials, hipStream_t st) {
   ResidentArgs a{};
@@ -1434,8 +1401,9 @@ void launch_resident(lbm_ctx *c, Slab &s, int src, int nsteps, bool accel_next, 
   hipEvent_t &ev = res_done[s.dev & 63];
   if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
   if (ev) (void)hipStreamWaitEvent(st, ev, 0);
-  if (s.res_bh == 2) launch_resident_bh<2>(s, a, st);
-  else launch_resident_bh<4>(s, a, st);
+  const dim3 grid(s.res_bands), block(64 * s.res_w);   // (the waves across a band are a launch parameter of the one kernel per band height)
+  if (s.res_bh == 2) hipLaunchKernelGGL((d2q9_resident<2>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((d2q9_resident<4>), grid, block, 0, st, a);
   if (ev) (void)hipEventRecord(ev, st);
 }
 
