@@ -1,8 +1,8 @@
 """World-size 2-4 `gloo` rehearsal of the row partition on CPU: every rank steps its slab with the oracle's
 row kernels, exchanges halo rows with its ring neighbours every `depth` steps (recomputing a shrinking
 halo region in between) and all-reduces the velocity sums — the protocol liblbm_hip.so runs per GPU with
-RCCL (csrc/lbm_hip.cpp: run_steps / exchange_halos) for halo depths 1, 2 (two-step kernel) and 8
-(d2q9_multi).  The result must equal the undivided oracle run bit for bit."""
+RCCL (csrc/lbm_hip.cpp: run_steps / exchange_halos) for halo depths 1, 2 (two-step kernel), 3, 4, 5 (the five-step
+chunk pairs of mid-size slabs) and 8 (d2q9_multi, the deep window kernel).  The result must equal the undivided oracle run bit for bit."""
 import os
 import socket
 import sys
@@ -86,7 +86,9 @@ def _rank_main(rank, world, port, size, nsteps, depth, out_dir):
 
 
 @pytest.mark.parametrize("world,size,nsteps,depth", [(2, "128x128", 40, 1), (3, "128x256", 25, 1), (2, "128x128", 21, 2),
-                                                     (2, "128x256", 27, 8), (4, "128x256", 16, 8), (3, "128x256", 22, 4), (2, "128x128", 14, 3)])
+                                                     (2, "128x256", 27, 8), (4, "128x256", 16, 8), (3, "128x256", 22, 4), (2, "128x128", 14, 3),
+                                                     # five halo rows per launch set of five steps: the slab pairs of round 4 (23 = 5+5+5+5+3)
+                                                     (2, "128x256", 23, 5), (4, "128x256", 17, 5)])
 def test_row_partition_protocol_matches_undivided_run(tmp_path, world, size, nsteps, depth):
     import torch.multiprocessing as mp
     import lbm_amd
