@@ -341,6 +341,30 @@ def test_final_state_and_reynolds(lbm, oracle_f32):
     assert abs(re / oracle_f32.reynolds(po, cells, obst) - 1.0) < 1e-4  # the oracle sums 16k terms in fp32
 
 
+def test_final_state_into_page_locked_memory(lbm):
+    """lbm_host_alloc / lbm_host_free (the read-back targets of the C host and of bench.py's reference-rule leg): the same
+    columns land in page-locked memory as in pageable memory, argument errors are refused, freeing twice is harmless"""
+    import ctypes
+    p, obst = lbm.read_inputs(*input_files("128x256"))
+    p.max_iters = 60
+    with lbm.LBM(p, obst) as sim:
+        sim.upload(None)
+        sim.run(60)
+        plain = sim.final_state()
+        buf = lbm.HostBuffer((4, p.ny, p.nx))
+        buf.array[:] = -1.0
+        pinned = sim.final_state(out=buf.array)
+        assert all(np.array_equal(a, b) for a, b in zip(plain, pinned))
+        assert np.array_equal(buf.array[3], plain[3]) and not np.any(buf.array == -1.0)
+        buf.close()
+        buf.close()
+    lib = lbm.load_library()
+    assert lib.lbm_host_alloc(None, 64) != 0 and b"bad argument" in lib.lbm_last_error()
+    ptr = ctypes.c_void_p()
+    assert lib.lbm_host_alloc(ctypes.byref(ptr), 0) != 0
+    assert lib.lbm_host_free(None) == 0
+
+
 # ---- row partition on one GPU (several slabs on device 0, halos by device-to-device copies) ----------
 
 @pytest.mark.parametrize("nslabs,ny", [(2, 50), (3, 50), (8, 50), (2, 16), (4, 67), (5, 128), (2, 260)])
