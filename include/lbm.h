@@ -235,10 +235,10 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "multistep"    T = 1..8: advance T timesteps per launch on LDS-resident tiles (small, launch-bound
  *                  grids), 0 = off, -1 = auto.  Single-slab grids only; takes precedence over "fuse".
  *   "resident"     1 = run all timesteps of an lbm_run (up to 256 per launch: the ring of per-step sums) in ONE launch with the
- *                  grid held in registers (d2q9_resident: bands of 2 or 4 full-width rows, one to eight waves across; neighbouring
+ *                  grid held in registers (d2q9_resident: bands of 2, 4 or 6 full-width rows, one to eight waves across; neighbouring
  *                  bands trade their edge rows through memory behind step words, bounded by "halo_timeout_ms") where the grid
  *                  allows it — one slab without halo rows, nx a multiple of 128 up to 1024, ny a multiple of the band height, all
- *                  bands resident on the device at once (up to 1M cells on 256 CUs) —, 0 = never, -1 = auto: from 200K cells
+ *                  bands resident on the device at once (up to 1.5M cells on 256 CUs) —, 0 = never, -1 = auto: from 200K cells
  *                  while "fuse" and "multistep" are on auto.  Reads back as the rows per band in use (0 = not in use).
  *                  Bit-identical to single steps.  A band that waits in vain ends the run with LBM_ERR_COMM.  Such a launch needs
  *                  the whole device: the library orders the resident launches of all contexts of a process one behind the other;

@@ -2250,7 +2250,7 @@ __global__ __launch_bounds__(128, 2) void d2q9_deep_twin(const Step2Args a, floa
 // The latency-bound sizes (512x512 ... 1024x1024: the sizes the reference publishes) pay, in every kernel above, a pass
 // through memory per launch and a launch per <= 8 steps: d2q9_deep_twin<5> runs 1024x1024 at 5.8 us/step, of which ~2.4 us is
 // arithmetic.  Here the grid never leaves the chip between the steps of an lbm_run: 1024x1024 cells x 36 B = 37.7 MB against
-// 128 MB of vector registers.  A WORKGROUP of W waves owns a band of BH full-width rows (W = nx / 128: a wave holds 64 lanes of
+// 128 MB of vector registers.  A WORKGROUP of W waves owns a band of BH (2, 4 or 6) full-width rows (W = nx / 128: a wave holds 64 lanes of
 // two cells x BH rows x 9 planes = 18 BH registers), one workgroup per CU at W = 8, all of them co-resident; per timestep
 //   - the waves of a band trade their edge cells (x neighbours, periodic wrap included) through LDS: one barrier;
 //   - a wave stores the three planes of its top row that move up and of its bottom row that move down into the band's
@@ -2440,7 +2440,7 @@ __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)
 
 template <int BH>
 __global__ __launch_bounds__(512) void d2q9_resident(const ResidentArgs a) {
-  static_assert(BH >= 2 && BH <= 4, "band shape");
+  static_assert(BH >= 2 && BH <= 6, "band shape");
   // x exchange inside the band: [parity][wave][row][3]: east[.] = planes 1,5,8 of the wave's last cell, west[.] = 3,6,7 of its first
   __shared__ float xe[2][8][BH][4], xw[2][8][BH][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

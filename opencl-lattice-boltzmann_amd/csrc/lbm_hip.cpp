@@ -481,21 +481,24 @@ bool fuse_effective(const lbm_ctx *c) { return fuse_level(c) != 0; }
 // all resident at once (two waves per SIMD: 8 / W workgroups per CU); res_* are set by resident_geometry.
 // Auto: from 200K cells (same-box A/B, us/step, the library's other choice / resident, profiles/r04_resident.txt: 256x256 1.79 / 2.13,
 // 128x2048 4.25 / 2.5, 512x512 3.87 / 2.54, 1024x512 5.17 / 3.08, 512x2048 6.41 / 3.74, 1024x1024 5.80 / 3.81); the kernel's limit is
-// what fits the registers of the chip at two waves per SIMD: 1M cells on 256 CUs.
+// what fits the registers of the chip at two waves per SIMD: 1.5M cells on 256 CUs (bands of six rows).
 bool resident_effective(const lbm_ctx *c) {
   if (c->halo_mode || c->slabs.size() != 1 || c->slabs[0].res_bands <= 0) return false;
   if (c->resident >= 0) return c->resident > 0;
   return c->fuse < 0 && c->multistep < 0 && (long)c->p.nx * c->p.ny >= 200L * 1024;
 }
-const void *resident_kernel(int bh) { return bh == 2 ? (const void *)d2q9_resident<2> : (const void *)d2q9_resident<4>; }
+const void *resident_kernel(int bh) {
+  return bh == 2 ? (const void *)d2q9_resident<2> : bh == 4 ? (const void *)d2q9_resident<4> : (const void *)d2q9_resident<6>;
+}
 int resident_geometry(const lbm_ctx *c, Slab &s) {
   s.res_bh = s.res_w = s.res_bands = 0;
   if (c->halo_mode || c->resident == 0 || c->p.nx % 128 != 0 || c->p.nx / 128 > 8) return LBM_OK;
   const int W = c->p.nx / 128;
   if (set_dev(s)) return LBM_ERR_HIP;
   int bh = 0;
-  for (int cand : {2, 4}) {  // the shortest bands that still fit the chip at once: most waves, least arithmetic per hand-shake
-                             // (bands of 8 rows — 144 registers of state — spill: 1M cells is the limit of this kernel)
+  for (int cand : {2, 4, 6}) {  // the shortest bands that still fit the chip at once: most waves, least arithmetic per hand-shake
+                                // (6 rows: 108 registers of state, 239 in all; bands of 8 rows — 144 — spill: 1.5M cells on 256 CUs is
+                                // the limit of this kernel)
     if (c->p.ny % cand != 0) continue;
     // every band must be resident at once (they wait for each other): what the runtime says a CU holds of this instantiation, capped
     // at the two waves per SIMD the schedules of this library plan with
@@ -1403,7 +1406,8 @@ void launch_resident(lbm_ctx *c, Slab &s, int src, int nsteps, bool accel_next, 
   if (ev) (void)hipStreamWaitEvent(st, ev, 0);
   const dim3 grid(s.res_bands), block(64 * s.res_w);   // (the waves across a band are a launch parameter of the one kernel per band height)
   if (s.res_bh == 2) hipLaunchKernelGGL((d2q9_resident<2>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((d2q9_resident<4>), grid, block, 0, st, a);
+  else if (s.res_bh == 4) hipLaunchKernelGGL((d2q9_resident<4>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((d2q9_resident<6>), grid, block, 0, st, a);
   if (ev) (void)hipEventRecord(ev, st);
 }
 
