@@ -237,7 +237,8 @@ int lbm_reynolds(lbm_ctx *ctx, float *reynolds_out);
  *   "resident"     1 = run all timesteps of an lbm_run (up to 256 per launch: the ring of per-step sums) in ONE launch with the
  *                  grid held in registers (d2q9_resident: bands of 2, 4 or 6 full-width rows, one to eight waves across; neighbouring
  *                  bands trade their edge rows through memory behind step words, bounded by "halo_timeout_ms") where the grid
- *                  allows it — one slab without halo rows, nx a multiple of 128 up to 1024, ny a multiple of the band height, all
+ *                  allows it — one slab without halo rows, nx a multiple of 4 from 128 to 1024 (a band's last wave may be partly filled), ny a
+ *                  multiple of the band height, all
  *                  bands resident on the device at once (up to 1.5M cells on 256 CUs) —, 0 = never, -1 = auto: from 200K cells
  *                  while "fuse" and "multistep" are on auto.  Reads back as the rows per band in use (0 = not in use).
  *                  Bit-identical to single steps.  A band that waits in vain ends the run with LBM_ERR_COMM.  Such a launch needs

@@ -2298,13 +2298,18 @@ __device__ __forceinline__ float resident_load1(const float *p) {
 // the kernel chooses ABOVE it: chosen per row inside the loop, the compiler merged the two collision paths into one that carries
 // the bounce-back selects and copies every row's result into place (916 VALU instructions per step of four rows, 251 of them moves,
 // 154 selects; the obstacle-free loop below has 555).  Both forms meet the same barriers.
-template <int BH, bool OBST>
+// PARTIAL: the band's last wave where nx is no multiple of 128 — its lanes from `nl` on hold no cell (they work on a copy of the last
+// pair and store nothing), and the "lane 63" of the x exchange is lane nl-1.
+template <int BH, bool OBST, bool PARTIAL>
 __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)[2][8][BH][4], float (&xw)[2][8][BH][4]) {
-  const int W = (int)(blockDim.x >> 6);   // waves across the band = nx / 128 (1 .. 8): a launch parameter, not a template one
+  const int W = (int)(blockDim.x >> 6);   // waves across the band = ceil(nx / 128) (1 .. 8): a launch parameter, not a template one
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int band = blockIdx.x, nbands = gridDim.x;
-  const int x0 = w * 128, xcol = x0 + 2 * lane;
+  const int x0 = w * 128;
+  const int nl = PARTIAL ? (a.nx - x0) / 2 : 64;           // lanes of this wave that hold cells
+  const bool active = !PARTIAL || lane < nl;
+  const int xcol = PARTIAL ? (lane < nl ? x0 + 2 * lane : a.nx - 2) : x0 + 2 * lane;   // (idle lanes read the row's last pair)
   const size_t ps = a.plane_stride, rs = a.row_stride;
   const int wl = (w + W - 1) % W, wr = (w + 1) % W;
   const int bdn = (band + nbands - 1) % nbands, bup = (band + 1) % nbands;
@@ -2324,6 +2329,7 @@ __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)
   const unsigned *poll = a.words + (size_t)(lane < 3 ? bdn : bup) * 32 + (lane % 3 == 0 ? wl : (lane % 3 == 1 ? w : wr));
   auto publish = [&](unsigned seq) __attribute__((always_inline)) {
     float *base = a.xrows + (size_t)(seq & 1u) * xr_par + (size_t)band * xr_band + xcol;
+    if (!active) return;
     resident_store(base + 0 * a.nx, f[BH - 1][2]);
     resident_store(base + 1 * a.nx, f[BH - 1][5]);
     resident_store(base + 2 * a.nx, f[BH - 1][6]);
@@ -2342,7 +2348,7 @@ __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)
     const int par = s & 1;
     const bool accel_ok = (s + 1 < a.nsteps) || a.accel_next;
     // ---- x neighbours through LDS
-    if (lane == 63) {
+    if (lane == nl - 1) {
 #pragma unroll
       for (int r = 0; r < BH; r++) { xe[par][w][r][0] = f[r][1].y; xe[par][w][r][1] = f[r][5].y; xe[par][w][r][2] = f[r][8].y; }
     }
@@ -2358,24 +2364,30 @@ __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)
       for (int k = 0; k < 3; k++) { hw[r][k] = xe[par][wl][r][k]; he[r][k] = xw[par][wr][r][k]; }
     }
     float sum = 0.f;
+    // (the pair shifted in from the east: lane 63 — in a partial wave lane nl-1 — takes the neighbour wave's first cell)
+    auto from_east = [&](v2f p, float halo) __attribute__((always_inline)) {
+      v2f r = pair_from_east(p, halo);
+      if (PARTIAL) r.y = (lane == nl - 1) ? halo : r.y;
+      return r;
+    };
     // one row: south = planes 2,5,6 of the row below (+ their x halos: west of 5, east of 6), north = planes 4,7,8 of the row above
     // (west of 8, east of 7)
     auto collide_row = [&](int r, const v2f (&south)[3], float s5w, float s6e, const v2f (&north)[3], float n8w, float n7e) __attribute__((always_inline)) {
       v2f g[9], o[9];
       g[0] = f[r][0];
       g[1] = pair_from_west(f[r][1], hw[r][0]);
-      g[3] = pair_from_east(f[r][3], he[r][0]);
+      g[3] = from_east(f[r][3], he[r][0]);
       g[2] = south[0];
       g[5] = pair_from_west(south[1], s5w);
-      g[6] = pair_from_east(south[2], s6e);
+      g[6] = from_east(south[2], s6e);
       g[4] = north[0];
-      g[7] = pair_from_east(north[1], n7e);
+      g[7] = from_east(north[1], n7e);
       g[8] = pair_from_west(north[2], n8w);
       const bool acc = accel_ok && (band * BH + r == a.accel_row);
       v2f t;
       if constexpr (!OBST) t = collide2<false>(g, 0u, a.omega, acc, a.aw1, a.aw2, o);
       else t = collide2<true>(g, m[r], a.omega, acc, a.aw1, a.aw2, o);
-      sum += t.x + t.y;
+      sum += active ? t.x + t.y : 0.f;
 #pragma unroll
       for (int k = 0; k < 9; k++) f[r][k] = o[k];
     };
@@ -2414,10 +2426,10 @@ __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)
 #pragma unroll
     for (int k = 0; k < 3; k++) { hb[k] = resident_load(below + k * a.nx + xcol); ha[k] = resident_load(above + k * a.nx + xcol); }
     // the corner elements: one cell beyond the wave's 128 (only lanes 0 and 63 use them)
-    const int xwest = (x0 + a.nx - 1) % a.nx, xeast = (x0 + 128) % a.nx;
+    const int xwest = (x0 + a.nx - 1) % a.nx, xeast = (x0 + 2 * nl) % a.nx;
     float b5w = 0.f, b6e = 0.f, a8w = 0.f, a7e = 0.f;
     if (lane == 0) { b5w = resident_load1(below + 1 * a.nx + xwest); a8w = resident_load1(above + 2 * a.nx + xwest); }
-    if (lane == 63) { b6e = resident_load1(below + 2 * a.nx + xeast); a7e = resident_load1(above + 1 * a.nx + xeast); }
+    if (lane == nl - 1) { b6e = resident_load1(below + 2 * a.nx + xeast); a7e = resident_load1(above + 1 * a.nx + xeast); }
     if constexpr (BH > 2) {
       collide_row(0, hb, b5w, b6e, one478, hw[1][2], he[1][2]);
     } else {
@@ -2430,11 +2442,13 @@ __device__ __forceinline__ void resident_band(const ResidentArgs &a, float (&xe)
     if (s + 1 < a.nsteps) raise_word(seq + 1u);
     if (lane == 0) a.partials[(size_t)s * a.pstride + band * W + w] = tot;
   }
+  if (active) {
 #pragma unroll
-  for (int r = 0; r < BH; r++) {
-    const size_t row = (size_t)(band * BH + r);
+    for (int r = 0; r < BH; r++) {
+      const size_t row = (size_t)(band * BH + r);
 #pragma unroll
-    for (int k = 0; k < 9; k++) *reinterpret_cast<v2f *>(a.dst + row * rs + k * ps + xcol) = f[r][k];
+      for (int k = 0; k < 9; k++) *reinterpret_cast<v2f *>(a.dst + row * rs + k * ps + xcol) = f[r][k];
+    }
   }
 }
 
@@ -2443,14 +2457,22 @@ __global__ __launch_bounds__(512) void d2q9_resident(const ResidentArgs a) {
   static_assert(BH >= 2 && BH <= 6, "band shape");
   // x exchange inside the band: [parity][wave][row][3]: east[.] = planes 1,5,8 of the wave's last cell, west[.] = 3,6,7 of its first
   __shared__ float xe[2][8][BH][4], xw[2][8][BH][4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int xcol = w * 128 + 2 * lane;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool partial = w * 128 + 128 > a.nx;   // the band's last wave where nx is no multiple of 128
+  const int xcol = w * 128 + 2 * lane < a.nx ? w * 128 + 2 * lane : a.nx - 2;
   uint32_t any = 0;
 #pragma unroll
   for (int r = 0; r < BH; r++)
     any |= (*reinterpret_cast<const uint32_t *>(a.mask + (size_t)(blockIdx.x * BH + r) * a.nx + (xcol & ~3)) >> ((xcol & 2) * 8)) & 0xffffu;
-  if (__builtin_amdgcn_ballot_w64(any != 0u) != 0ull) resident_band<BH, true>(a, xe, xw);
-  else resident_band<BH, false>(a, xe, xw);
+  const bool obst = __builtin_amdgcn_ballot_w64(any != 0u) != 0ull;
+  if (partial) {
+    if (obst) resident_band<BH, true, true>(a, xe, xw);
+    else resident_band<BH, false, true>(a, xe, xw);
+  } else if (obst) {
+    resident_band<BH, true, false>(a, xe, xw);
+  } else {
+    resident_band<BH, false, false>(a, xe, xw);
+  }
 }
 
 // ---- T timesteps per launch on an LDS-resident tile (small grids) ---------------------------------

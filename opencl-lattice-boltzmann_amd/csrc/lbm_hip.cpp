@@ -492,8 +492,9 @@ const void *resident_kernel(int bh) {
 }
 int resident_geometry(const lbm_ctx *c, Slab &s) {
   s.res_bh = s.res_w = s.res_bands = 0;
-  if (c->halo_mode || c->resident == 0 || c->p.nx % 128 != 0 || c->p.nx / 128 > 8) return LBM_OK;
-  const int W = c->p.nx / 128;
+  // (nx: a multiple of 4 — the mask is read a dword at a time — up to 1024; a band's last wave may be partly filled)
+  if (c->halo_mode || c->resident == 0 || c->p.nx % 4 != 0 || c->p.nx < 128 || c->p.nx > 1024) return LBM_OK;
+  const int W = div_up(c->p.nx, 128);
   if (set_dev(s)) return LBM_ERR_HIP;
   int bh = 0;
   for (int cand : {2, 4, 6}) {  // the shortest bands that still fit the chip at once: most waves, least arithmetic per hand-shake

@@ -120,7 +120,9 @@ def test_two_steps_per_launch_equals_single_steps(lbm, oracle_f32_omp, nx, ny, c
 
 
 @pytest.mark.parametrize("nx,ny,bh", [(128, 6, 2), (128, 4, 2), (256, 64, 2), (512, 512, 2), (1024, 512, 2), (1024, 1024, 4), (512, 2048, 4), (128, 4100, 4),
-                                      (384, 64, 2), (640, 512, 2), (768, 768, 4), (896, 256, 2), (1024, 1536, 6), (512, 3072, 6), (1024, 1200, 6)])
+                                      (384, 64, 2), (640, 512, 2), (768, 768, 4), (896, 256, 2), (1024, 1536, 6), (512, 3072, 6), (1024, 1200, 6),
+                                      # widths that are no multiple of 128: the band's last wave is partly filled
+                                      (1000, 1000, 4), (260, 512, 2), (132, 64, 2), (900, 600, 4), (1020, 1536, 6), (516, 96, 2)])
 @pytest.mark.parametrize("nsteps,split", [(1, 0), (2, 0), (7, 3), (23, 0), (300, 0)])
 def test_resident_kernel_equals_single_steps(lbm, nx, ny, bh, nsteps, split):
     """d2q9_resident: all steps of an lbm_run in ONE launch with the grid in registers — bands of 2 or 4 full-width rows, one to
@@ -205,10 +207,10 @@ def test_default_kernel_choice_by_grid_size(lbm):
     for bandwidth-bound ones, the deep window kernel above 300K cells — as chunk pairs (d2q9_deep_twin), with up to five steps
     per launch below 3M cells and up to eight from there on; grids of fewer than 32 rows, which the deep kernel does not take, fall
     back to the two- / three-step kernels; and, round 4, the resident kernel (all steps of a launch with the grid in registers)
-    from 200K to 1.5M cells where the grid is a multiple of 128 cells (up to 1024) wide and its bands of 2, 4 or 6 rows all fit the chip at once"""
+    from 200K to 1.5M cells where the grid is a multiple of 4 cells (128 to 1024) wide and its bands of 2, 4 or 6 rows all fit the chip at once"""
     expect = {(128, 128): (8, 0, 8), (256, 256): (8, 0, 8), (512, 512): "resident 2", (640, 512): "resident 2", (768, 512): "resident 2", (1024, 512): "resident 2", (1152, 512): (0, 8, 5),
               (16384, 24): (0, 1, 2), (32768, 24): (0, 3, 3), (512, 384): (8, 0, 8),
-              (768, 768): "resident 4", (1024, 1024): "resident 4", (1024, 1536): "resident 6", (1024, 2048): (0, 8, 5), (1024, 1028): (0, 8, 5), (1536, 1024): (0, 8, 5), (2048, 1024): (0, 8, 5), (2048, 2048): (0, 8, 8),
+              (768, 768): "resident 4", (1024, 1024): "resident 4", (1024, 1536): "resident 6", (1024, 2048): (0, 8, 5), (1000, 1000): "resident 4", (1002, 1000): (0, 0, 1), (1024, 1028): (0, 8, 5), (1536, 1024): (0, 8, 5), (2048, 1024): (0, 8, 5), (2048, 2048): (0, 8, 8),
               (3072, 2048): (0, 8, 8), (4096, 2048): (0, 8, 8), (8192, 1024): (0, 8, 8), (128, 8192): "resident 4", (128, 8200): (0, 0, 1)}
     for (nx, ny), want in expect.items():
         ob = np.zeros((ny, nx), np.int32)
