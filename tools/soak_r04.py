@@ -38,7 +38,8 @@ def make(nx, ny, nsteps, blocked=0.04, walls=False):
 
 # (kind, case, creation keywords, creation defaults, options)
 jobs = []
-for (nx, ny, nsteps) in ((1024, 1024, 300), (512, 512, 97), (768, 768, 64), (1024, 512, 257), (128, 2048, 40), (896, 1024, 33)):
+for (nx, ny, nsteps) in ((1024, 1024, 300), (512, 512, 97), (768, 768, 64), (1024, 512, 257), (128, 2048, 40), (896, 1024, 33),
+                         (1000, 1000, 120), (900, 600, 77), (1020, 1536, 45), (260, 2048, 30)):   # (partly filled last waves; bands of six rows)
     c = make(nx, ny, nsteps)
     jobs.append(("resident", c, {}, {}, {"resident": 1}))
 for (nx, ny, nsteps, slabs) in ((1024, 1024, 23, 2), (2048, 1024, 36, 4), (1024, 2000, 19, 3)):
