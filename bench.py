@@ -1129,9 +1129,10 @@ def main():
                 w2 = time.perf_counter() - t1
                 f2 = s2.get_option("launch_steps")
                 k2 = kernel_label({k: s2.get_option(k) for k in OPTION_KEYS})
-            out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat (d2q9_resident: the grid is read and written once per "
-                                       "launch of up to 256 timesteps and held in registers in between; what moves per step is 13 MB of exchange "
-                                       "rows, served on-die — profiles/r04c3.txt; both grids fit the 256 MiB Infinity Cache either way)",
+            note = ("the grid is read and written once per launch of up to 256 timesteps and held in registers in between; what moves per step is "
+                    "13 MB of exchange rows, served on-die — profiles/r04c3.txt" if "resident" in k2 else
+                    "both grids fit the 256 MiB Infinity Cache: these bytes come from cache, not HBM — profiles/r02_config3.txt")
+            out["also"] = {"workload": "input_1024x1024.params + obstacles_1024x1024.dat (%s)" % note,
                            "value": round(1024 * 1024 * n2 / w2 / 1e6, 1), "unit": "MLUPS", "steps": n2, "us_per_step": round(ms2 / n2 * 1e3, 3),
                            "steps_per_launch": f2, "kernel": k2,
                            "model_gbps": round((BYTES_PER_LU + MASK_BYTES) * 1024 * 1024 / (ms2 * 1e-3 / n2 * f2) / 1e9, 1),
